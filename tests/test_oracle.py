@@ -1,0 +1,124 @@
+"""CPU: the oracle (oracle/cpu_ref.py) against the golden vectors generated from the reference
+(oracle/gen_golden.py).  Tolerance: max-abs error <= 1e-4 * max-abs(ref), fp32."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from mikudance_amd.synth import synth_state_dict
+from oracle import cpu_ref as O
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+
+def test_g1_windows(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "g1_windows.json"))):
+        got = O.uniform_windows(0, case["steps"], case["num_frames"], case["context_frames"], 1, case["overlap"])
+        assert got == case["windows"], case
+
+
+def test_g2_scene_motion(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g2_scene_motion.npz"))
+    flow = O.camera_to_scene_motion(list(z["w2c"]), list(z["c2w"]), list(z["K"]), z["depth"], 24, 24, False)
+    assert np.abs(flow - z["flow"]).max() <= 1e-12
+    assert np.abs(z["flow"]).max() > 1e-3
+    eye = [np.eye(4)] * 5
+    assert np.abs(O.camera_to_scene_motion(eye, eye, list(z["K"]), np.zeros((1, 24, 24)), 24, 24)).max() == 0
+    assert np.abs(z["flow_identity"]).max() == 0
+
+
+def _sd(shapes, seed):
+    return synth_state_dict(shapes, seed=seed)
+
+
+def test_g3_blocks(golden_dir):
+    t = load_file(os.path.join(golden_dir, "g3_blocks.safetensors"))
+    x5, temb = t["resnet.x"], t["resnet.temb"]
+    b, c, f, h, w = x5.shape
+    fold = lambda v: v.permute(0, 2, 1, 3, 4).reshape(-1, v.shape[1], v.shape[3], v.shape[4])
+    unfold = lambda v: v.reshape(b, f, v.shape[1], v.shape[2], v.shape[3]).permute(0, 2, 1, 3, 4)
+    rs = {"norm1.weight": (32,), "norm1.bias": (32,), "conv1.weight": (64, 32, 3, 3), "conv1.bias": (64,),
+          "time_emb_proj.weight": (64, 128), "time_emb_proj.bias": (64,), "norm2.weight": (64,), "norm2.bias": (64,),
+          "conv2.weight": (64, 64, 3, 3), "conv2.bias": (64,), "conv_shortcut.weight": (64, 32, 1, 1),
+          "conv_shortcut.bias": (64,)}
+    y = O.resnet(_sd(rs, 11), "", fold(x5), temb.repeat_interleave(f, 0))
+    assert rel(unfold(y), t["resnet.y"]) < 1e-4
+    rs2 = {k: ((64,) + v[1:] if k in ("norm1.weight", "norm1.bias") else v) for k, v in rs.items()
+           if not k.startswith("conv_shortcut")}
+    rs2["conv1.weight"] = (64, 64, 3, 3)
+    y2 = O.resnet(_sd(rs2, 12), "", y, temb.repeat_interleave(f, 0))
+    assert rel(unfold(y2), t["resnet_same.y"]) < 1e-4
+    cs = {"conv.weight": (64, 64, 3, 3), "conv.bias": (64,)}
+    assert rel(unfold(O.downsample(_sd(cs, 13), "", y)), t["down.y"]) < 1e-4
+    assert rel(unfold(O.upsample(_sd(cs, 14), "", y)), t["up.y"]) < 1e-4
+    ms = {"mlp_shared.0.weight": (128, 2, 3, 3), "mlp_shared.0.bias": (128,), "mlp_gamma.weight": (64, 128, 3, 3),
+          "mlp_gamma.bias": (64,), "mlp_beta.weight": (64, 128, 3, 3), "mlp_beta.bias": (64,)}
+    assert rel(O.man_module(_sd(ms, 15), "", t["man.x"], t["man.motion"]), t["man.y"]) < 1e-4
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "g4_g5_meta.json")))
+    shapes = json.load(open(os.path.join(golden_dir, "g6_state_dict_keys_small.json")))
+    den_sd = synth_state_dict(shapes["denoising_unet"], seed=meta["seed_den"])
+    ref_sd = synth_state_dict(shapes["reference_unet"], seed=meta["seed_ref"])
+    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
+    assert abs(cs(ref_sd) - meta["checksum_ref"]) < 1e-6 * meta["checksum_ref"]
+    t = load_file(os.path.join(golden_dir, "g4_g5_unets.safetensors"))
+    return meta, ref_sd, den_sd, t
+
+
+def test_g4_unets(small):
+    meta, ref_sd, den_sd, t = small
+    latents, ref_latents, embeds = t["in.latents"], t["in.ref_latents"], t["in.embeds"]
+    win, f = [0, 1, 2, 3], 4
+    with torch.no_grad():
+        g = ref_latents[:, win].repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, 16, 16)
+        banks, ref_out = O.reference_unet_forward(ref_sd, g, embeds.repeat((f, 1, 1)))
+        assert rel(ref_out[f:], t["g4.ref_out_cond"]) < 1e-4
+        n = 0
+        for k, v in banks.items():
+            gold = t["bank." + k.rstrip(".")]
+            assert gold.dtype == torch.float16
+            # fp16-rounded reference bank vs our fp32 bank: half-ulp relative 2^-11 of each value
+            assert ((v[f:] - gold.float()).abs() <= 1.2e-3 * gold.float().abs() + 1e-4).all(), k
+            n += 1
+        assert n == 16
+        banks16 = {k: v.half().float() for k, v in banks.items()}
+        x = latents[:, :, win].repeat(2, 1, 1, 1, 1)
+        pred = O.denoising_unet_forward(den_sd, x, torch.tensor(601), embeds, banks16, cfg=True)
+        assert rel(pred, t["g4.pred"]) < 1e-4
+
+
+def test_g5_loop_literal_and_reduced(small):
+    meta, ref_sd, den_sd, t = small
+    g5 = meta["g5"]
+    got = {}
+    with torch.no_grad():
+        for reduced in (False, True):
+            snaps = {}
+            O.denoise_loop(ref_sd, den_sd, t["in.latents"], t["in.ref_latents"], t["in.embeds"], g5["steps"],
+                           guidance_scale=g5["guidance"], context_frames=g5["context_frames"], context_stride=1,
+                           context_overlap=g5["overlap"], reduced=reduced,
+                           on_step=lambda ts, lat: snaps.__setitem__(ts, lat.clone()))
+            got[reduced] = snaps
+    for ts in g5["timesteps"]:
+        gold = t[f"g5.latents_after_t{ts}"]
+        assert rel(got[False][ts], gold) < 2e-4, ts
+        # result-preserving reductions (ref UNet once per window, consumed frames only) change nothing
+        assert rel(got[True][ts], got[False][ts]) < 1e-5, ts
+
+
+def test_g7_ddim(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g7_ddim_restated.json")))
+    sch = O.DDIM()
+    assert [int(x) for x in sch.set_timesteps(20)] == g["timesteps_20"] == list(range(999, 0, -50))
+    assert float(sch.alphas_cumprod[-1]) == 0.0          # zero terminal SNR
+    x = torch.randn(2, 3); v = torch.randn(2, 3)
+    assert torch.allclose(sch.step(v, 999, x), (sch.coeffs(999)[1] ** 0.5) * (-v) + ((1 - sch.coeffs(999)[1]) ** 0.5) * x)
