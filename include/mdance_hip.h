@@ -1,0 +1,102 @@
+/* libmdance_hip.so -- C ABI of the MI355X (gfx950) denoising-loop kernels.
+ *
+ * The reference (Kebii/MikuDance) has NO FFI on this path: every hot-path FLOP is a stock PyTorch/ATen call made
+ * from Python.  The boundary is therefore op-level: each entry point below replaces the
+ * ATen dispatches of the cited reference call sites (paths relative to the reference repository root).  The
+ * reference-side binding is a ctypes stub; mikudance_amd/_lib.py is that stub in this repo.
+ *
+ * Conventions: all device pointers are raw addresses owned by the caller (PyTorch-ROCm allocates them); nothing is
+ * allocated, freed or retained; kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call
+ * returns immediately.  Activations are fp16, token-major / NHWC: a (B,H,W,C) image batch IS the row-major matrix
+ * [B*H*W][C].  Weights are fp16 [N][K] with K contiguous (nn.Linear layout; 3x3 conv weights as
+ * [Cout][ky][kx][Cin]).  Return value: 0 on success, negative on error (md_last_error() has the message);
+ * thread-safe for distinct streams.
+ */
+#ifndef MDANCE_HIP_H
+#define MDANCE_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_ACT_NONE 0
+#define MD_ACT_SILU 1
+#define MD_ACT_RELU 2
+#define MD_ACT_GEGLU 3 /* W rows packed as alternating blocks of 32 'h' rows and 32 'g' rows; C gets N/2 columns */
+
+int md_version(void);
+const char* md_last_error(void);
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T): bias[N], act, rowadd[(m / rows_per_group)][n] (time-embedding broadcast),
+ * residual[M,N] (added last), or transpose_out (C is [N][ldc], used for V^T).  K % 64 == 0.
+ * Replaces nn.Linear / 1x1 Conv2d: diffusers Attention.to_q/to_k/to_v/to_out.0 and FeedForward
+ * (src/models/attention.py:109-157,323-364), proj_in/proj_out (src/models/transformer_3d.py:66-68,96-98;
+ * src/models/transformer_2d.py:152-154,186-188; src/models/motion_module.py:124,146), conv_shortcut and
+ * time_emb_proj (src/models/resnet.py:179-181,213-215), TimestepEmbedding (src/models/unet_3d_mix.py:99-102). */
+int md_gemm_f16(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, const void* bias,
+                const void* residual, int ldr, const void* rowadd, int ldra, int rows_per_group, int act,
+                int transpose_out, void* stream);
+
+/* Y = epi(conv3x3(X)) on NHWC, zero padding 1, stride 1|2, upsample=1 folds a nearest-2x upsample into the input
+ * addressing.  Cin % 64 == 0 (zero-pad when packing).  Output (B, Hout, Wout, Cout) with row pitch ldy.
+ * Replaces InflatedConv3d / Conv2d 3x3: src/models/resnet.py:9-17,71-88,106-120,165-167,194-196;
+ * src/models/unet_3d_mix.py:94-96,267-269; src/models/unet_2d_mix.py:321-326; src/models/man_module.py:18-21. */
+int md_conv3x3_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout,
+                        int stride, int upsample, const void* bias, const void* residual, int ldr,
+                        const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
+
+/* GroupNorm(G, eps) [+SiLU] over (B, HW, C) NHWC.  src/models/resnet.py:20-28,220-221,231,237;
+ * src/models/transformer_3d.py:60-62,130; src/models/motion_module.py:121-123,164; unet_3d_mix.py:591-592. */
+size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G);
+int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G,
+                          float eps, int silu, void* workspace, size_t ws_bytes, void* stream);
+
+/* LayerNorm over rows of C.  add_mode 0: y only.  add_mode 1: y2[row] = y[row] + add[row - add_row_begin] for
+ * rows >= add_row_begin (reference-attention bank ADD, src/models/mutual_mix_attention.py:169-170), y2 = y
+ * below.  add_mode 2: y2[row] = y[row] + add[(row / rows_per_frame) % frames] (temporal positional encoding on the
+ * query input only, src/models/motion_module.py:404-417).  src/models/attention.py:105-107,331-365. */
+int md_layernorm_f16(const void* x, void* y, void* y2, const void* gamma, const void* beta, const void* add, int M,
+                     int C, float eps, int add_mode, int add_row_begin, int rows_per_frame, int frames, void* stream);
+
+/* MAN: y = InstanceNorm(x) * (1 + gamma) + beta; gamma_beta is (B, HW, 2C) = [gamma | beta].
+ * src/models/man_module.py:23-33. */
+int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void* y, int B, int HW, int C, float eps,
+                          void* stream);
+
+/* O = softmax(Q K^T * scale) V per (batch, head); Vt is V transposed ([H*D][ldvt], md_gemm_f16 transpose_out);
+ * kv_index (device int[B], may be NULL) maps a query batch to its K/V batch; kv_stride = tokens between K/V batches.
+ * D in {8,16,32,40,64,80,160}.  Replaces F.scaled_dot_product_attention under diffusers AttnProcessor2_0 as
+ * called at src/models/mutual_mix_attention.py:141-148,173-200,213-220,257-263. */
+int md_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                         const int* kv_index, int B, int H, int D, int Lq, int Lk, int kv_stride, float scale,
+                         void* stream);
+
+/* Attention over FRAMES for every (clip-half, pixel, head); rows are (b*F + frame)*HW + pixel.  F <= 32.
+ * src/models/motion_module.py:364-439 (VersatileAttention, Temporal mode). */
+int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                                  int ldo, int NB, int F, int HW, int H, int D, float scale, void* stream);
+
+/* Layout packing at the API boundary (any strided fp16/fp32 source -> NHWC fp16 with zero channel padding and
+ * nearest sub-sampling; and back).  src/models/unet_2d_mix.py:1208-1210 (22-channel split),
+ * src/models/man_module.py:27 (nearest resize), einops rearranges of src/models/resnet.py:12-16. */
+int md_pack_nhwc_f16(const void* src, int src_is_f32, void* dst, int N, int F, long sB, long sF, long sC, long sY,
+                     long sX, int c_begin, int c_count, int Cpad, int Ho, int Wo, int sub, void* stream);
+int md_unpack_nhwc_f16(const void* src, int ldc, void* dst, int dst_is_f32, int N, int F, long sB, long sF, long sC,
+                       long sY, long sX, int C, int Ho, int Wo, void* stream);
+
+/* torch.cat([hidden, skip], dim=channel) on token-major matrices.  src/models/unet_3d_blocks.py:736,877. */
+int md_concat_channels_f16(const void* a, int Ca, const void* b, int Cb, void* out, long M, void* stream);
+
+/* noise_pred[:, :, window] += pred; counter[window] += 1.  src/pipelines/pipeline_mikudance.py:662-664. */
+int md_window_accumulate(const void* pred, void* noise_sum, void* counter, const int* window, int f, int Ftot, int HW,
+                         int halves, void* stream);
+
+/* (noise_pred / counter) -> classifier-free guidance -> DDIM v-prediction step (eta 0), latents updated in place.
+ * src/pipelines/pipeline_mikudance.py:670-678 + diffusers DDIMScheduler.step. */
+int md_cfg_ddim_step(void* latents, const void* noise_sum, const void* counter, int Ftot, int HW, int halves,
+                     float guidance, float alpha_t, float alpha_prev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,65 @@
+"""ctypes binding of libmdance_hip.so (the C ABI declared in include/mdance_hip.h).
+
+There is NO fallback: if the shared library is missing the first op call raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C mikudance_amd/csrc`.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdance_hip.so")
+
+P = c_void_p
+SIGNATURES = {
+    "md_version": (c_int, []),
+    "md_last_error": (c_char_p, []),
+    "md_gemm_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "md_conv3x3_nhwc_f16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int,
+                                    c_int, c_int, P]),
+    "md_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "md_groupnorm_nhwc_f16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
+    "md_layernorm_f16": (c_int, [P, P, P, P, P, P, c_int, c_int, c_float, c_int, c_int, c_int, c_int, P]),
+    "md_instnorm_spade_f16": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
+    "md_attention_fwd_f16": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_float, P]),
+    "md_temporal_attention_fwd_f16": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                              c_float, P]),
+    "md_pack_nhwc_f16": (c_int, [P, c_int, P, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, c_int, c_int,
+                                 c_int, c_int, c_int, P]),
+    "md_unpack_nhwc_f16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, c_int,
+                                   c_int, P]),
+    "md_concat_channels_f16": (c_int, [P, c_int, P, c_int, P, c_long, P]),
+    "md_window_accumulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "md_cfg_ddim_step": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P]),
+}
+
+_lib = None
+
+
+class MdanceHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the library.  Raises if it has not been built: the product path never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdanceHipError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (run __graft_entry__.build()). "
+                "mikudance_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MdanceHipError(f"{name} failed ({rc}): {lib.md_last_error().decode()}")

@@ -1,0 +1,259 @@
+// HBM-bound normalisation kernels on NHWC / token-major fp16 activations (wavefront reductions, 16-B loads).
+//   md_groupnorm_nhwc_f16 : GroupNorm(G, eps) [+ SiLU]  -- reference src/models/resnet.py:20-28,220-221,231,237
+//                           (InflatedGroupNorm) and the eps=1e-6 norms of transformer_3d.py:60-62 / motion_module.py:121-123
+//   md_layernorm_f16      : LayerNorm(C) with optional second output y + bank (mutual_mix_attention.py:169-170) or
+//                           y + positional encoding of the row's frame (motion_module.py:416-417)
+//   md_instnorm_spade_f16 : InstanceNorm2d(x) * (1 + gamma) + beta   -- src/models/man_module.py:25-31
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// Thread (cc, r): channel chunk cc (8 channels), row lane r.  A block owns `slab` consecutive pixels of one image.
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int R, int slab, int nslab) {
+  extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq
+  const int cch = C >> 3;
+  const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int p0 = sl * slab, p1 = min(p0 + slab, HW);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  const half_t* base = x + (size_t)b * HW * C + cc * 8;
+  for (int p = p0 + r; p < p1; p += R) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(base + (size_t)p * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[e];
+      s[e] += f;
+      q[e] += f * f;
+    }
+  }
+  float* ss = sh;
+  float* sq = sh + R * C;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ss[r * C + cc * 8 + e] = s[e];
+    sq[r * C + cc * 8 + e] = q[e];
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, c2 = 0.f;
+    for (int rr = 0; rr < R; ++rr)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a += ss[rr * C + c];
+        c2 += sq[rr * C + c];
+      }
+    float* o = part + (((size_t)b * nslab + sl) * G + g) * 2;
+    o[0] = a;
+    o[1] = c2;
+  }
+}
+
+__global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ part, const half_t* __restrict__ gamma,
+                                const half_t* __restrict__ beta, int HW, int C, int G, int R, int slab, int nslab, float eps, int silu) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int cch = C >> 3;
+  const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, c2 = 0.f;
+    const float* pp = part + ((size_t)b * nslab * G + g) * 2;
+    for (int k = 0; k < nslab; ++k) {
+      a += pp[(size_t)k * G * 2];
+      c2 += pp[(size_t)k * G * 2 + 1];
+    }
+    const float n = (float)HW * (float)cpg;
+    const float mu = a / n;
+    const float var = fmaxf(c2 / n - mu * mu, 0.f);
+    mean_s[g] = mu;
+    rstd_s[g] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  float sc[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cc * 8 + e;
+    const int g = c / cpg;
+    sc[e] = rstd_s[g] * (float)gamma[c];
+    sf[e] = (float)beta[c] - mean_s[g] * sc[e];
+  }
+  const int p0 = sl * slab, p1 = min(p0 + slab, HW);
+  const size_t base = (size_t)b * HW * C + cc * 8;
+  for (int p = p0 + r; p < p1; p += R) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(x + base + (size_t)p * C);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v[e] * sc[e] + sf[e];
+      if (silu) f = silu_f(f);
+      o[e] = (half_t)f;
+    }
+    *reinterpret_cast<half8_t*>(y + base + (size_t)p * C) = o;
+  }
+}
+
+extern "C" size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
+  const int cch = C / 8;
+  int R = 512 / cch;
+  if (R < 1) R = 1;
+  const int slab = R * 16;
+  const int nslab = cdiv(HW, slab);
+  return (size_t)B * nslab * G * 2 * sizeof(float);
+}
+
+extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps, int silu,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+  MD_CHECK_ARG(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0, "md_groupnorm: need C %% 8 == 0, G <= 64, C %% G == 0 (C=%d G=%d)", C, G);
+  MD_CHECK_ARG(C / 8 <= 1024, "md_groupnorm: C=%d too large", C);
+  MD_CHECK_ARG(ws_bytes >= md_groupnorm_workspace_bytes(B, HW, C, G), "md_groupnorm: workspace too small");
+  const int cch = C / 8;
+  int R = 512 / cch;
+  if (R < 1) R = 1;
+  const int slab = R * 16;
+  const int nslab = cdiv(HW, slab);
+  dim3 grid(nslab, B), block(cch * R);
+  const size_t sh = (size_t)2 * R * C * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, HW, C, G, R, slab, nslab);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const half_t*)gamma,
+                     (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu);
+  MD_CHECK_LAUNCH("md_groupnorm");
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, row held in registers (C <= 8*64*MAXC).
+#define LN_MAXC 4
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, half_t* __restrict__ y2,
+                                                        const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                        const half_t* __restrict__ add, int M, int C, float eps, int add_mode, int add_row_begin,
+                                                        int rows_per_frame, int frames) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cch = C >> 3;
+  float v[LN_MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) {
+    const int c = lane + k * 64;
+    if (c < cch) {
+      const half8_t h = *reinterpret_cast<const half8_t*>(x + (size_t)row * C + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[k][e] = (float)h[e];
+        sum += v[k][e];
+      }
+    }
+  }
+  const float mu = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) {
+    const int c = lane + k * 64;
+    if (c < cch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[k][e] - mu;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  const half_t* addp = nullptr;
+  if (add_mode == 1 && row >= add_row_begin) addp = add + (size_t)(row - add_row_begin) * C;  // bank rows
+  if (add_mode == 2) addp = add + (size_t)((row / rows_per_frame) % frames) * C;            // positional encoding of the frame
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) {
+    const int c = lane + k * 64;
+    if (c < cch) {
+      const half8_t g = *reinterpret_cast<const half8_t*>(gamma + c * 8);
+      const half8_t bt = *reinterpret_cast<const half8_t*>(beta + c * 8);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[k][e] - mu) * rstd * (float)g[e] + (float)bt[e]);
+      *reinterpret_cast<half8_t*>(y + (size_t)row * C + c * 8) = o;
+      if (y2) {
+        half8_t o2 = o;
+        if (addp) {
+          const half8_t a = *reinterpret_cast<const half8_t*>(addp + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o2[e] = (half_t)((float)o[e] + (float)a[e]);  // fp16 n + fp16 bank, one rounding
+        }
+        *reinterpret_cast<half8_t*>(y2 + (size_t)row * C + c * 8) = o2;
+      }
+    }
+  }
+}
+
+extern "C" int md_layernorm_f16(const void* x, void* y, void* y2, const void* gamma, const void* beta, const void* add, int M, int C, float eps,
+                                int add_mode, int add_row_begin, int rows_per_frame, int frames, void* stream) {
+  MD_CHECK_ARG(C % 8 == 0 && C <= 8 * 64 * LN_MAXC, "md_layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXC);
+  MD_CHECK_ARG(add_mode == 0 || (add != nullptr && y2 != nullptr), "md_layernorm: add_mode needs add and y2");
+  MD_CHECK_ARG(add_mode != 2 || (rows_per_frame > 0 && frames > 0), "md_layernorm: add_mode 2 needs rows_per_frame and frames");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (half_t*)y2, (const half_t*)gamma,
+                     (const half_t*)beta, (const half_t*)add, M, C, eps, add_mode, add_row_begin, rows_per_frame, frames);
+  MD_CHECK_LAUNCH("md_layernorm");
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ InstanceNorm + SPADE
+// Block = 64 channels (8 chunks) x 32 row lanes of one image; two passes over HW (second pass is L2 resident).
+__global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gb, half_t* __restrict__ y, int HW,
+                                                             int C, float eps) {
+  __shared__ float ss[32][64], sq[32][64], mean_s[64], rstd_s[64];
+  const int cc = threadIdx.x & 7, r = threadIdx.x >> 3;
+  const int b = blockIdx.y, c0 = blockIdx.x * 64 + cc * 8;
+  const half_t* xb = x + (size_t)b * HW * C + c0;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  for (int p = r; p < HW; p += 32) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[e];
+      s[e] += f;
+      q[e] += f * f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ss[r][cc * 8 + e] = s[e];
+    sq[r][cc * 8 + e] = q[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float a = 0.f, c2 = 0.f;
+    for (int rr = 0; rr < 32; ++rr) {
+      a += ss[rr][threadIdx.x];
+      c2 += sq[rr][threadIdx.x];
+    }
+    const float mu = a / (float)HW;
+    mean_s[threadIdx.x] = mu;
+    rstd_s[threadIdx.x] = rsqrtf(fmaxf(c2 / (float)HW - mu * mu, 0.f) + eps);
+  }
+  __syncthreads();
+  const half_t* gbb = gb + (size_t)b * HW * 2 * C + c0;
+  half_t* yb = y + (size_t)b * HW * C + c0;
+  for (int p = r; p < HW; p += 32) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * C);
+    const half8_t ga = *reinterpret_cast<const half8_t*>(gbb + (size_t)p * 2 * C);
+    const half8_t be = *reinterpret_cast<const half8_t*>(gbb + (size_t)p * 2 * C + C);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float n = ((float)v[e] - mean_s[cc * 8 + e]) * rstd_s[cc * 8 + e];
+      o[e] = (half_t)(n * (1.f + (float)ga[e]) + (float)be[e]);
+    }
+    *reinterpret_cast<half8_t*>(yb + (size_t)p * C) = o;
+  }
+}
+
+extern "C" int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void* y, int B, int HW, int C, float eps, void* stream) {
+  MD_CHECK_ARG(C % 64 == 0, "md_instnorm_spade: C=%d must be a multiple of 64", C);
+  hipLaunchKernelGGL(instnorm_spade_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)gamma_beta, (half_t*)y, HW,
+                     C, eps);
+  MD_CHECK_LAUNCH("md_instnorm_spade");
+  return MD_OK;
+}

@@ -1,0 +1,190 @@
+"""Thin tensor-level wrappers over the C ABI (include/mdance_hip.h).  PyTorch supplies device memory and the
+stream; all arithmetic happens in the HIP kernels.  Every function requires CUDA(ROCm) fp16 tensors and raises
+otherwise -- there is no eager/CPU fallback."""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU = 0, 1, 2, 3
+F16 = torch.float16
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, name, dtype=F16):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.MdanceHipError(f"{name} must live on the GPU: mikudance_amd has no CPU path")
+    if t.dtype != dtype:
+        raise _lib.MdanceHipError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _rowmajor(t, name):
+    _chk(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.MdanceHipError(f"{name} must be a 2-D row-major matrix (stride(1) == 1)")
+    return t.stride(0)
+
+
+def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, transpose_out=False, out=None,
+         ldc_t=None):
+    """out[M, N] = epi(a[M, K] @ w[N, K]^T).  transpose_out: out is [N, ldc_t] (V^T for attention)."""
+    lda = _rowmajor(a, "a")
+    _chk(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous(), (w.shape, K)
+    if out is None:
+        if transpose_out:
+            out = torch.empty((N, ldc_t or M), device=a.device, dtype=F16)
+        else:
+            out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), device=a.device, dtype=F16)
+    ldc = _rowmajor(out, "out")
+    ldr = _rowmajor(residual, "residual") if residual is not None else 0
+    ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
+    _chk(bias, "bias")
+    _lib.call("md_gemm_f16", a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias), _p(residual), ldr,
+              _p(rowadd), ldra, rows_per_group, act, int(transpose_out), _st())
+    return out
+
+
+def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, stride=1, upsample=False,
+            out=None):
+    """x: (B, H, W, Cin) NHWC contiguous; w: [Cout, 9*Cin] packed (ky, kx, cin); returns (B, Ho, Wo, Cout)."""
+    _chk(x, "x")
+    _chk(w, "w")
+    assert x.dim() == 4 and x.is_contiguous()
+    B, H, W, Cin = x.shape
+    assert w.shape == (cout, 9 * Cin) and w.is_contiguous(), (w.shape, cout, Cin)
+    hup, wup = (H * 2, W * 2) if upsample else (H, W)
+    Ho, Wo = (hup - 1) // stride + 1, (wup - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=F16)
+    o2 = out.view(-1, out.shape[-1])
+    ldy = _rowmajor(o2, "out")
+    r2 = residual.view(-1, residual.shape[-1]) if residual is not None else None
+    ldr = _rowmajor(r2, "residual") if r2 is not None else 0
+    ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
+    _chk(bias, "bias")
+    _lib.call("md_conv3x3_nhwc_f16", x.data_ptr(), w.data_ptr(), out.data_ptr(), ldy, B, H, W, Cin, cout, stride,
+              int(upsample), _p(bias), _p(r2), ldr, _p(rowadd), ldra, rows_per_group, act, _st())
+    return out
+
+
+_gn_ws = {}
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False, out=None):
+    """x: (B, HW, C) or (B, H, W, C) NHWC contiguous."""
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    assert x.is_contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    need = _lib.load().md_groupnorm_workspace_bytes(B, HW, C, groups)
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((max(need, 1 << 20) + 3) // 4, device=x.device, dtype=torch.float32)
+        _gn_ws[key] = ws
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("md_groupnorm_nhwc_f16", x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, C, groups,
+              float(eps), int(silu), ws.data_ptr(), ws.numel() * 4, _st())
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, add=None, add_mode=0, add_row_begin=0, rows_per_frame=0, frames=0):
+    """x: [M, C].  Returns y (add_mode 0) or (y, y2)."""
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta"); _chk(add, "add")
+    assert x.dim() == 2 and x.is_contiguous()
+    M, C = x.shape
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if add_mode else None
+    _lib.call("md_layernorm_f16", x.data_ptr(), y.data_ptr(), _p(y2), gamma.data_ptr(), beta.data_ptr(), _p(add), M, C,
+              float(eps), add_mode, add_row_begin, rows_per_frame, frames, _st())
+    return (y, y2) if add_mode else y
+
+
+def instnorm_spade(x, gamma_beta, eps=1e-5):
+    """x: (B, HW, C); gamma_beta: (B, HW, 2C)."""
+    _chk(x, "x"); _chk(gamma_beta, "gamma_beta")
+    assert x.is_contiguous() and gamma_beta.is_contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    _lib.call("md_instnorm_spade_f16", x.data_ptr(), gamma_beta.data_ptr(), y.data_ptr(), B, HW, C, float(eps), _st())
+    return y
+
+
+def attention(q, k, vt, B, H, D, Lq, Lk, kv_stride=None, kv_index=None, scale=None, out=None):
+    """q [B*Lq, >=H*D], k [nkv*kv_stride, >=H*D], vt [H*D, >=nkv*kv_stride] (V transposed) -> out [B*Lq, H*D]."""
+    ldq = _rowmajor(q, "q"); ldk = _rowmajor(k, "k"); ldvt = _rowmajor(vt, "vt")
+    if kv_index is not None:
+        _chk(kv_index, "kv_index", torch.int32)
+    if out is None:
+        out = torch.empty((B * Lq, H * D), device=q.device, dtype=F16)
+    ldo = _rowmajor(out, "out")
+    _lib.call("md_attention_fwd_f16", q.data_ptr(), ldq, k.data_ptr(), ldk, vt.data_ptr(), ldvt, out.data_ptr(), ldo,
+              _p(kv_index), B, H, D, Lq, Lk, kv_stride if kv_stride is not None else Lk,
+              float(scale if scale is not None else D ** -0.5), _st())
+    return out
+
+
+def temporal_attention(q, k, v, NB, F, HW, H, D, out=None):
+    """q/k/v: [(NB*F)*HW, >=H*D] token-major (frame-major rows).  Attention across the F frames of every pixel."""
+    ldq = _rowmajor(q, "q"); ldk = _rowmajor(k, "k"); ldv = _rowmajor(v, "v")
+    if out is None:
+        out = torch.empty((NB * F * HW, H * D), device=q.device, dtype=F16)
+    ldo = _rowmajor(out, "out")
+    _lib.call("md_temporal_attention_fwd_f16", q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(), ldo,
+              NB, F, HW, H, D, float(D ** -0.5), _st())
+    return out
+
+
+def pack_nhwc(src, n, f, strides, c_begin, c_count, cpad, ho, wo, sub=1):
+    """Strided gather into a fresh (n, ho, wo, cpad) fp16 NHWC tensor.  strides = (sB, sF, sC, sY, sX) in elements."""
+    if not src.is_cuda or src.dtype not in (torch.float16, torch.float32):
+        raise _lib.MdanceHipError("pack_nhwc: source must be a CUDA fp16/fp32 tensor")
+    dst = torch.empty((n, ho, wo, cpad), device=src.device, dtype=F16)
+    sB, sF, sC, sY, sX = strides
+    _lib.call("md_pack_nhwc_f16", src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(), n, f, sB, sF, sC, sY, sX,
+              c_begin, c_count, cpad, ho, wo, sub, _st())
+    return dst
+
+
+def unpack_nhwc(src, dst, n, f, strides, c, ho, wo):
+    """Scatter NHWC fp16 `src` (n, ho, wo, ldc>=c) into the strided fp16/fp32 tensor `dst`."""
+    _chk(src, "src")
+    sB, sF, sC, sY, sX = strides
+    _lib.call("md_unpack_nhwc_f16", src.data_ptr(), src.shape[-1], dst.data_ptr(), int(dst.dtype == torch.float32), n, f, sB,
+              sF, sC, sY, sX, c, ho, wo, _st())
+    return dst
+
+
+def concat_channels(a, b):
+    _chk(a, "a"); _chk(b, "b")
+    assert a.is_contiguous() and b.is_contiguous() and a.shape[:-1] == b.shape[:-1]
+    out = torch.empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), device=a.device, dtype=F16)
+    _lib.call("md_concat_channels_f16", a.data_ptr(), a.shape[-1], b.data_ptr(), b.shape[-1], out.data_ptr(),
+              a.numel() // a.shape[-1], _st())
+    return out
+
+
+def window_accumulate(pred, noise_sum, counter, window, f, ftot, hw, halves=2):
+    _chk(pred, "pred"); _chk(noise_sum, "noise_sum", torch.float32); _chk(counter, "counter", torch.float32)
+    _chk(window, "window", torch.int32)
+    _lib.call("md_window_accumulate", pred.data_ptr(), noise_sum.data_ptr(), counter.data_ptr(), window.data_ptr(), f, ftot,
+              hw, halves, _st())
+
+
+def cfg_ddim_step(latents, noise_sum, counter, ftot, hw, guidance, alpha_t, alpha_prev, halves=2):
+    _chk(latents, "latents"); _chk(noise_sum, "noise_sum", torch.float32); _chk(counter, "counter", torch.float32)
+    _lib.call("md_cfg_ddim_step", latents.data_ptr(), noise_sum.data_ptr(), counter.data_ptr(), ftot, hw, halves,
+              float(guidance), float(alpha_t), float(alpha_prev), _st())

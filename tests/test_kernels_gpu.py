@@ -1,0 +1,286 @@
+"""GPU: every HIP kernel, called through the C ABI (mikudance_amd.ops -> libmdance_hip.so), against an fp32 PyTorch
+restatement of the same op (the oracle's leaf ops) fed the SAME fp16-rounded inputs.
+Tolerance: |err| <= 1e-2 * maxabs(ref) + 1e-3  (fp16 io, fp32 accumulate)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mikudance_amd import ops, packing  # noqa: E402
+from oracle import cpu_ref as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+def close(got, ref, rtol=1e-2, atol=1e-3, what=""):
+    got = got.float().cpu()
+    ref = ref.float()
+    err = (got - ref).abs().max().item()
+    bound = rtol * ref.abs().max().item() + atol
+    assert math.isfinite(err) and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (7, 320, 64), (130, 4, 64), (1000, 1288, 320)])
+def test_gemm_plain_edges(dev, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    # asymmetric operands: catches row/col or fragment transposes
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a.to(dev), w.to(dev))
+    close(out, ref, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_identity_asymmetric(dev):
+    K = 128
+    a = torch.eye(K).half()
+    w = (torch.arange(K * K).reshape(K, K) % 97).half() / 16
+    out = ops.gemm(a.to(dev), w.to(dev))            # = W^T
+    assert torch.equal(out.cpu().float(), w.float().t())
+
+
+def test_gemm_epilogues(dev):
+    M, N, K = 384, 320, 256
+    a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+    bias, res, radd = rnd(N, seed=5), rnd(M, N, seed=6), rnd(3, N, seed=7)
+    base = a.float() @ w.float().t() + bias.float()
+    d = lambda t: t.to(dev)
+    close(ops.gemm(d(a), d(w), bias=d(bias)), base, what="bias")
+    close(ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_SILU), F.silu(base), what="silu")
+    close(ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_RELU), F.relu(base), what="relu")
+    close(ops.gemm(d(a), d(w), bias=d(bias), residual=d(res)), base + res.float(), what="residual")
+    ref = base + radd.float().repeat_interleave(128, 0)
+    close(ops.gemm(d(a), d(w), bias=d(bias), rowadd=d(radd), rows_per_group=128), ref, what="rowadd")
+    # strided A (a column slice of a wider matrix) and strided residual
+    wide = rnd(M, 2 * K, seed=8)
+    close(ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t(), what="lda")
+
+
+def test_gemm_transpose_out(dev):
+    for M, N, K in [(264, 128, 64), (521, 320, 128), (36, 64, 64)]:
+        a, w = rnd(M, K, seed=9), rnd(N, K, seed=10, scale=K ** -0.5)
+        out = ops.gemm(a.to(dev), w.to(dev), transpose_out=True)
+        assert out.shape == (N, M)
+        close(out, (a.float() @ w.float().t()).t(), what=f"transpose {M}")
+
+
+def test_gemm_geglu(dev):
+    M, K, inner = 200, 128, 256
+    a = rnd(M, K, seed=11)
+    w, b = rnd(2 * inner, K, seed=12, scale=K ** -0.5), rnd(2 * inner, seed=13)
+    hg = a.float() @ w.float().t() + b.float()
+    ref = hg[:, :inner] * F.gelu(hg[:, inner:])
+    wp, bp = packing.geglu_weight(w, b, dev)
+    out = ops.gemm(a.to(dev), wp, bias=bp, act=ops.ACT_GEGLU)
+    assert out.shape == (M, inner)
+    close(out, ref, what="geglu")
+
+
+def test_gemm_rejects_bad_k(dev):
+    from mikudance_amd._lib import MdanceHipError
+    with pytest.raises(MdanceHipError):
+        ops.gemm(rnd(8, 40).to(dev), rnd(8, 40).to(dev))
+
+
+# --------------------------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("cin,cout,h,w,stride,up", [(64, 64, 8, 8, 1, False), (20, 64, 9, 7, 1, False), (128, 192, 12, 12, 2, False),
+                                                    (64, 128, 6, 5, 1, True), (4, 4, 16, 16, 1, False), (64, 64, 7, 7, 2, False)])
+def test_conv3x3(dev, cin, cout, h, w, stride, up):
+    B = 3
+    x = rnd(B, cin, h, w, seed=20)
+    wt = rnd(cout, cin, 3, 3, seed=21, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=22)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, wt.float(), bias.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    cp = packing.pad_to(cin, 64)
+    xn = torch.zeros(B, h, w, cp, dtype=torch.float16)
+    xn[..., :cin] = x.permute(0, 2, 3, 1)
+    out = ops.conv3x3(xn.to(dev), packing.conv3x3_weight(wt, dev), cout, bias=bias.to(dev), stride=stride, upsample=up)
+    assert tuple(out.shape) == tuple(ref.shape)
+    close(out, ref, what="conv")
+
+
+def test_conv3x3_fused_temb_residual(dev):
+    B, c, h, w = 4, 64, 8, 8
+    x, wt, bias = rnd(B, h, w, c, seed=23), rnd(c, c, 3, 3, seed=24, scale=(9 * c) ** -0.5), rnd(c, seed=25)
+    temb, res = rnd(2, c, seed=26), rnd(B, h, w, c, seed=27)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + temb.float().repeat_interleave(2, 0)[:, None, None, :] + res.float()
+    out = ops.conv3x3(x.to(dev), packing.conv3x3_weight(wt, dev), c, bias=bias.to(dev), residual=res.to(dev),
+                      rowadd=temb.to(dev), rows_per_group=2 * h * w)
+    close(out, ref, what="conv+temb+res")
+
+
+# --------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,HW,C,silu,eps", [(2, 64, 64, True, 1e-5), (3, 100, 320, False, 1e-6), (2, 37, 960, True, 1e-5),
+                                             (1, 2304, 640, True, 1e-5), (2, 16, 2560, False, 1e-5)])
+def test_groupnorm(dev, B, HW, C, silu, eps):
+    x = rnd(B, HW, C, seed=30) * 2 + 0.5
+    g, b = (1 + 0.1 * rnd(C, seed=31).float()).half(), rnd(C, seed=32)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, g.float(), b.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    close(ops.groupnorm(x.to(dev), g.to(dev), b.to(dev), 32, eps, silu), ref, what="groupnorm")
+
+
+@pytest.mark.parametrize("M,C", [(10, 64), (301, 320), (64, 1280), (5, 256)])
+def test_layernorm_and_adds(dev, M, C):
+    x = rnd(M, C, seed=33) * 3 + 1
+    g, b = (1 + 0.1 * rnd(C, seed=34).float()).half(), rnd(C, seed=35)
+    ref = F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5)
+    close(ops.layernorm(x.to(dev), g.to(dev), b.to(dev)), ref, what="ln")
+    half = M // 2
+    bank = rnd(M - half, C, seed=36)
+    y, y2 = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), add=bank.to(dev), add_mode=1, add_row_begin=half)
+    close(y, ref, what="ln y")
+    ref2 = ref.clone()
+    ref2[half:] += bank.float()
+    close(y2, ref2, what="ln + bank")
+    frames, rpf = 3, 2
+    pe = rnd(frames, C, seed=37)
+    y, y2 = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), add=pe.to(dev), add_mode=2, rows_per_frame=rpf, frames=frames)
+    idx = (torch.arange(M) // rpf) % frames
+    close(y2, ref + pe.float()[idx], what="ln + pe")
+
+
+def test_instnorm_spade(dev):
+    B, HW, C = 3, 144, 128
+    x, gb = rnd(B, HW, C, seed=38) * 2 + 1, rnd(B, HW, 2 * C, seed=39)
+    n = F.instance_norm(x.float().permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    ref = n * (1 + gb.float()[..., :C]) + gb.float()[..., C:]
+    close(ops.instnorm_spade(x.to(dev), gb.to(dev)), ref, what="man")
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, B, H, D, Lq, Lk, kv_index=None):
+    qh = q.float().view(B, Lq, H, D).transpose(1, 2)
+    nkv = k.shape[0] // Lk
+    kh = k.float().view(nkv, Lk, H, D).transpose(1, 2)
+    vh = v.float().view(nkv, Lk, H, D).transpose(1, 2)
+    if kv_index is not None:
+        kh, vh = kh[kv_index], vh[kv_index]
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(B * Lq, H * D)
+
+
+@pytest.mark.parametrize("D,Lq,Lk", [(8, 256, 256), (16, 64, 64), (32, 16, 16), (32, 4, 4), (40, 200, 333), (80, 130, 64),
+                                     (160, 144, 144), (64, 33, 257), (40, 576, 576)])
+def test_attention_self(dev, D, Lq, Lk):
+    B, H = 2, 8
+    q, k, v = rnd(B * Lq, H * D, seed=40), rnd(B * Lk, H * D, seed=41), rnd(B * Lk, H * D, seed=42)
+    ref = _attn_ref(q, k, v, B, H, D, Lq, Lk)
+    vt = v.t().contiguous()
+    out = ops.attention(q.to(dev), k.to(dev), vt.to(dev), B, H, D, Lq, Lk)
+    close(out, ref, what=f"attn D={D}")
+
+
+def test_attention_forces_rescale(dev):
+    """Online softmax: a late key dominating one query row forces the max-rescale branch (CDNA guide rule 26)."""
+    B, H, D, L = 1, 8, 40, 320
+    q, k, v = rnd(L, H * D, seed=43), rnd(L, H * D, seed=44), rnd(L, H * D, seed=45)
+    k[300] = q[5] * 4
+    ref = _attn_ref(q, k, v, B, H, D, L, L)
+    out = ops.attention(q.to(dev), k.to(dev), v.t().contiguous().to(dev), B, H, D, L, L)
+    close(out, ref, what="attn rescale")
+
+
+def test_attention_cross_padded_kv_index(dev):
+    """Lk = 257 CLIP tokens, K/V batches padded to a stride of 264, query batches mapped through kv_index."""
+    B, H, D, Lq, Lk, stride = 6, 8, 40, 100, 257, 264
+    q = rnd(B * Lq, H * D, seed=46)
+    kk, vv = rnd(2, Lk, H * D, seed=47), rnd(2, Lk, H * D, seed=48)
+    kpad, vpad = torch.zeros(2, stride, H * D).half(), torch.zeros(2, stride, H * D).half()
+    kpad[:, :Lk], vpad[:, :Lk] = kk, vv
+    idx = torch.tensor([0, 1, 1, 0, 1, 0], dtype=torch.int32)
+    ref = _attn_ref(q, kk.reshape(-1, H * D), vv.reshape(-1, H * D), B, H, D, Lq, Lk, kv_index=idx.long())
+    out = ops.attention(q.to(dev), kpad.reshape(-1, H * D).to(dev), vpad.reshape(-1, H * D).t().contiguous().to(dev), B, H, D,
+                        Lq, Lk, kv_stride=stride, kv_index=idx.to(dev))
+    close(out, ref, what="cross attn")
+
+
+def test_attention_via_gemm_vt(dev):
+    """V^T produced by the GEMM's transposed store feeds attention directly (the production data flow)."""
+    B, H, D, L, C = 2, 8, 40, 96, 320
+    x, wv = rnd(B * L, C, seed=49), rnd(C, C, seed=50, scale=C ** -0.5)
+    q, k = rnd(B * L, C, seed=51), rnd(B * L, C, seed=52)
+    v = (x.float() @ wv.float().t()).half()
+    ref = _attn_ref(q, k, v, B, H, D, L, L)
+    vt = ops.gemm(x.to(dev), wv.to(dev), transpose_out=True)
+    out = ops.attention(q.to(dev), k.to(dev), vt, B, H, D, L, L)
+    close(out, ref, rtol=2e-2, what="attn via gemm")
+
+
+@pytest.mark.parametrize("F_,HW,D", [(4, 16, 8), (16, 9, 40), (6, 5, 32), (24, 4, 80), (32, 3, 160), (30, 7, 40)])
+def test_temporal_attention(dev, F_, HW, D):
+    NB, H = 2, 8
+    C = H * D
+    q, k, v = rnd(NB * F_ * HW, C, seed=53), rnd(NB * F_ * HW, C, seed=54), rnd(NB * F_ * HW, C, seed=55)
+
+    def fold(t):  # (b f) d c -> (b d) f c -> heads
+        return t.float().view(NB, F_, HW, H, D).permute(0, 2, 3, 1, 4)      # b d h f D
+    o = F.scaled_dot_product_attention(fold(q), fold(k), fold(v))          # b d h f D
+    ref = o.permute(0, 3, 1, 2, 4).reshape(NB * F_ * HW, C)
+    out = ops.temporal_attention(q.to(dev), k.to(dev), v.to(dev), NB, F_, HW, H, D)
+    close(out, ref, what="temporal")
+
+
+# --------------------------------------------------------------------------------------------- elementwise
+def test_pack_unpack_concat(dev):
+    b, c, f, h, w = 2, 4, 3, 8, 6
+    x = torch.randn(b, c, f, h, w, generator=torch.Generator().manual_seed(60))
+    xd = x.to(dev)
+    st = xd.stride()
+    p = ops.pack_nhwc(xd, b * f, f, (st[0], st[2], st[1], st[3], st[4]), 0, c, 64, h, w)
+    ref = torch.zeros(b * f, h, w, 64)
+    ref[..., :c] = x.permute(0, 2, 3, 4, 1).reshape(b * f, h, w, c)
+    assert torch.equal(p.cpu().float(), ref.half().float())
+    # channel sub-range + nearest sub-sampling (motion map of MAN)
+    m = torch.randn(5, 22, 16, 16, generator=torch.Generator().manual_seed(61)).half().to(dev)
+    st = m.stride()
+    pm = ops.pack_nhwc(m, 5, 1, (st[0], 0, st[1], st[2], st[3]), 20, 2, 64, 4, 4, sub=4)
+    refm = F.interpolate(m[:, 20:].float().cpu(), size=(4, 4), mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(pm.cpu().float()[..., :2], refm)
+    assert pm[..., 2:].abs().max().item() == 0
+    # unpack back to NCFHW fp32
+    y = torch.zeros(b, c, f, h, w, device=dev)
+    st = y.stride()
+    ops.unpack_nhwc(p, y, b * f, f, (st[0], st[2], st[1], st[3], st[4]), c, h, w)
+    assert torch.equal(y.cpu(), x.half().float())
+    a, bb = rnd(7, 5, 64, seed=62), rnd(7, 5, 128, seed=63)
+    assert torch.equal(ops.concat_channels(a.to(dev), bb.to(dev)).cpu(), torch.cat([a, bb], -1))
+
+
+def test_window_accumulate_and_ddim(dev):
+    Ftot, f, HW = 6, 4, 20
+    sch = O.DDIM()
+    sch.set_timesteps(4)
+    lat = rnd(Ftot, HW, 4, seed=64)
+    noise = torch.zeros(2, Ftot, HW, 4, device=dev)
+    cnt = torch.zeros(Ftot, device=dev)
+    ref_noise, ref_cnt = torch.zeros(2, Ftot, HW, 4), torch.zeros(Ftot)
+    for wi, win in enumerate([[0, 1, 2, 3], [2, 3, 4, 5], [4, 5, 0, 1]]):
+        pred = rnd(2 * f, HW, 4, seed=70 + wi)
+        ops.window_accumulate(pred.to(dev), noise, cnt, torch.tensor(win, dtype=torch.int32, device=dev), f, Ftot, HW)
+        for h_ in range(2):
+            ref_noise[h_, win] += pred.float().view(2, f, HW, 4)[h_]
+        ref_cnt[win] += 1
+    assert torch.allclose(noise.cpu(), ref_noise, atol=1e-6) and torch.equal(cnt.cpu(), ref_cnt)
+    u, c = (ref_noise / ref_cnt[None, :, None, None]).chunk(2)
+    v = (u + 3.5 * (c - u))[0]
+    t = 749
+    ref = sch.step(v, t, lat.float())
+    a_t, a_prev = sch.coeffs(t)
+    latd = lat.to(dev).clone()
+    ops.cfg_ddim_step(latd, noise, cnt, Ftot, HW, 3.5, a_t, a_prev)
+    close(latd, ref, rtol=2e-3, atol=2e-3, what="ddim")
