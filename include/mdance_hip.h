@@ -77,10 +77,10 @@ int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk
                                   int ldo, int NB, int F, int HW, int H, int D, float scale, void* stream);
 
 /* Layout packing at the API boundary (any strided fp16/fp32 source -> NHWC fp16 with zero channel padding and
- * nearest sub-sampling; and back).  src/models/unet_2d_mix.py:1208-1210 (22-channel split),
+ * nearest resize (Hin,Win)->(Ho,Wo); and back).  src/models/unet_2d_mix.py:1208-1210 (22-channel split),
  * src/models/man_module.py:27 (nearest resize), einops rearranges of src/models/resnet.py:12-16. */
 int md_pack_nhwc_f16(const void* src, int src_is_f32, void* dst, int N, int F, long sB, long sF, long sC, long sY,
-                     long sX, int c_begin, int c_count, int Cpad, int Ho, int Wo, int sub, void* stream);
+                     long sX, int c_begin, int c_count, int Cpad, int Ho, int Wo, int Hin, int Win, void* stream);
 int md_unpack_nhwc_f16(const void* src, int ldc, void* dst, int dst_is_f32, int N, int F, long sB, long sF, long sC,
                        long sY, long sX, int C, int Ho, int Wo, void* stream);
 

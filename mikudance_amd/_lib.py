@@ -26,7 +26,7 @@ SIGNATURES = {
     "md_temporal_attention_fwd_f16": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                               c_float, P]),
     "md_pack_nhwc_f16": (c_int, [P, c_int, P, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, c_int, c_int,
-                                 c_int, c_int, c_int, P]),
+                                 c_int, c_int, c_int, c_int, P]),
     "md_unpack_nhwc_f16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, c_int,
                                    c_int, P]),
     "md_concat_channels_f16": (c_int, [P, c_int, P, c_int, P, c_long, P]),

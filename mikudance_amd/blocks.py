@@ -1,0 +1,403 @@
+"""Building blocks shared by the two UNets.  Every module owns parameters under the REFERENCE's state-dict key
+names (so the reference's .pth / SD-1.5 checkpoints load unchanged) and runs on NHWC fp16 activations through the
+HIP kernels in mikudance_amd.ops.  Packed (kernel-layout) weights are built lazily and dropped whenever parameters
+are reloaded or moved.
+
+Activation convention: a (B, H, W, C) fp16 contiguous tensor; its 2-D view [B*H*W, C] is the token matrix, so the
+reference's NCHW<->token shuffles (src/models/transformer_3d.py:121,134-136,185-189,201;
+src/models/motion_module.py:159,166-168,182-189,404-406,437) do not exist here.
+"""
+import torch
+from torch import nn
+
+from . import ops, packing
+
+GROUPS = 32
+HEADS = 8
+
+
+class _Packed(nn.Module):
+    """nn.Module with a lazily built cache of kernel-layout weights."""
+
+    def __init__(self):
+        super().__init__()
+        self._pk = None
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def packed(self):
+        if self._pk is None:
+            with torch.no_grad():
+                self._pk = self._pack(next(self.parameters()).device)
+        return self._pk
+
+
+class Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+
+
+class Conv(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+
+
+class Affine(nn.Module):
+    """weight/bias of a GroupNorm or LayerNorm."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c))
+        self.bias = nn.Parameter(torch.empty(c))
+
+
+def tokens(x):
+    return x.view(-1, x.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------------ ResnetBlock
+class ResnetBlock(_Packed):
+    """ResnetBlock3D / diffusers ResnetBlock2D (reference src/models/resnet.py:123-247):
+    GN+SiLU -> conv3x3 (+time_emb_proj(silu(temb)) fused as a row broadcast) -> GN+SiLU -> conv3x3 (+shortcut fused)."""
+
+    def __init__(self, cin, cout, temb_ch, eps=1e-5):
+        super().__init__()
+        self.cin, self.cout, self.eps = cin, cout, eps
+        self.norm1 = Affine(cin)
+        self.conv1 = Conv(cin, cout, 3)
+        self.time_emb_proj = Linear(temb_ch, cout)
+        self.norm2 = Affine(cout)
+        self.conv2 = Conv(cout, cout, 3)
+        self.conv_shortcut = Conv(cin, cout, 1) if cin != cout else None
+
+    def _pack(self, dev):
+        pk = dict(n1w=packing.vec(self.norm1.weight, dev), n1b=packing.vec(self.norm1.bias, dev),
+                  n2w=packing.vec(self.norm2.weight, dev), n2b=packing.vec(self.norm2.bias, dev),
+                  c1=packing.conv3x3_weight(self.conv1.weight, dev), c1b=packing.vec(self.conv1.bias, dev),
+                  c2=packing.conv3x3_weight(self.conv2.weight, dev), c2b=packing.vec(self.conv2.bias, dev))
+        if self.conv_shortcut is not None:
+            pk["sc"] = packing.conv1x1_weight(self.conv_shortcut.weight, dev)
+            pk["scb"] = packing.vec(self.conv_shortcut.bias, dev)
+        return pk
+
+    def forward(self, x, temb, rows_per_group):
+        """x (B,H,W,cin); temb [groups, cout] = time_emb_proj(silu(emb)) rows (already projected, see TimeEmbedding)."""
+        pk = self.packed()
+        h = ops.groupnorm(x, pk["n1w"], pk["n1b"], GROUPS, self.eps, silu=True)
+        h = ops.conv3x3(h, pk["c1"], self.cout, bias=pk["c1b"], rowadd=temb, rows_per_group=rows_per_group)
+        h = ops.groupnorm(h, pk["n2w"], pk["n2b"], GROUPS, self.eps, silu=True)
+        if self.conv_shortcut is not None:
+            sc = ops.gemm(tokens(x), pk["sc"], bias=pk["scb"]).view(x.shape[:-1] + (self.cout,))
+        else:
+            sc = x
+        return ops.conv3x3(h, pk["c2"], self.cout, bias=pk["c2b"], residual=sc)
+
+
+class ConvSampler(_Packed):
+    """Downsample (3x3 stride 2 pad 1) or Upsample (nearest 2x folded into the 3x3 conv's addressing).
+    reference src/models/resnet.py:31-120; key `conv.{weight,bias}`."""
+
+    def __init__(self, c, up):
+        super().__init__()
+        self.c, self.up = c, up
+        self.conv = Conv(c, c, 3)
+
+    def _pack(self, dev):
+        return dict(w=packing.conv3x3_weight(self.conv.weight, dev), b=packing.vec(self.conv.bias, dev))
+
+    def forward(self, x):
+        pk = self.packed()
+        if self.up:
+            return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], upsample=True)
+        return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], stride=2)
+
+
+# ------------------------------------------------------------------------------------------------ attention / FF
+class Attention(nn.Module):
+    """Parameter holder for diffusers Attention (bias-free q/k/v, biased to_out.0)."""
+
+    def __init__(self, dim, kv_dim=None):
+        super().__init__()
+        self.to_q = Linear(dim, dim, bias=False)
+        self.to_k = Linear(kv_dim or dim, dim, bias=False)
+        self.to_v = Linear(kv_dim or dim, dim, bias=False)
+        self.to_out = nn.ModuleList([Linear(dim, dim)])
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = Linear(dim, dim * 8)
+
+
+class FeedForward(nn.Module):
+    """diffusers FeedForward(geglu): keys net.0.proj.*, net.2.*"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([_GEGLU(dim), nn.Identity(), Linear(dim * 4, dim)])
+
+
+def _pack_ff(ff, dev, pk, prefix="ff"):
+    w, b = packing.geglu_weight(ff.net[0].proj.weight, ff.net[0].proj.bias, dev)
+    pk[prefix + "1"], pk[prefix + "1b"] = w, b
+    pk[prefix + "2"], pk[prefix + "2b"] = packing.linear_weight(ff.net[2].weight, dev), packing.vec(ff.net[2].bias, dev)
+
+
+def _run_ff(pk, n, resid, prefix="ff"):
+    g = ops.gemm(n, pk[prefix + "1"], bias=pk[prefix + "1b"], act=ops.ACT_GEGLU)
+    return ops.gemm(g, pk[prefix + "2"], bias=pk[prefix + "2b"], residual=resid)
+
+
+class CrossContext:
+    """Per-forward cross-attention context: `ctx` [(nkv*Lpad), Dctx] zero-padded rows, `index` int32[B] mapping each
+    frame to its context batch, Lk valid tokens, Lpad stride.  K/V projections of the context are cached per block
+    (step-invariant; SURVEY.md 2.2 'cross k/v')."""
+
+    def __init__(self, ctx, index, lk, lpad, key):
+        self.ctx, self.index, self.lk, self.lpad, self.key = ctx, index, lk, lpad, key
+
+
+class TransformerBlock(_Packed):
+    """BasicTransformerBlock (2-D, reference src/models/attention.py:12-295) and TemporalBasicTransformerBlock (3-D,
+    :298-484) share parameters; behaviour is selected by the reference-attention mode set through
+    ReferenceAttentionControl (reference src/models/mutual_mix_attention.py:93-280):
+      None    : plain self-attn -> cross-attn -> FF
+      "write" : same, and bank = [norm1(x)]
+      "read"  : K/V source = norm1(x) + bank on the conditional rows, plain on the unconditional rows (CFG)."""
+
+    def __init__(self, dim, ctx_dim, heads=HEADS, kind="2d"):
+        super().__init__()
+        self.dim, self.heads, self.kind = dim, heads, kind
+        self.norm1 = Affine(dim)
+        self.attn1 = Attention(dim)
+        self.norm2 = Affine(dim)
+        self.attn2 = Attention(dim, ctx_dim)
+        self.norm3 = Affine(dim)
+        self.ff = FeedForward(dim)
+        self.bank = []
+        self.ref_mode = None
+        self.ref_cfg = False
+        self.stop_after_bank = False      # last writer block: everything after the bank write is dead code
+        self._kv_cache = {}
+
+    def _pack(self, dev):
+        L, V = packing.linear_weight, packing.vec
+        a1, a2 = self.attn1, self.attn2
+        pk = {f"n{i}w": V(n.weight, dev) for i, n in ((1, self.norm1), (2, self.norm2), (3, self.norm3))}
+        pk.update({f"n{i}b": V(n.bias, dev) for i, n in ((1, self.norm1), (2, self.norm2), (3, self.norm3))})
+        pk["q1"], pk["k1"], pk["v1"] = L(a1.to_q.weight, dev), L(a1.to_k.weight, dev), L(a1.to_v.weight, dev)
+        pk["qk1"] = torch.cat([pk["q1"], pk["k1"]], 0).contiguous()
+        pk["o1"], pk["o1b"] = L(a1.to_out[0].weight, dev), V(a1.to_out[0].bias, dev)
+        pk["q2"], pk["k2"], pk["v2"] = L(a2.to_q.weight, dev), L(a2.to_k.weight, dev), L(a2.to_v.weight, dev)
+        pk["o2"], pk["o2b"] = L(a2.to_out[0].weight, dev), V(a2.to_out[0].bias, dev)
+        _pack_ff(self.ff, dev, pk)
+        self._kv_cache = {}
+        return pk
+
+    def forward(self, h, B, L, cross):
+        """h: [B*L, C] tokens.  Returns tokens."""
+        pk = self.packed()
+        C, H = self.dim, self.heads
+        D = C // H
+        if self.ref_mode == "read" and len(self.bank) == 1:
+            bank = self.bank[0]
+            brows = bank.shape[0] * bank.shape[1] if bank.dim() == 3 else bank.shape[0]
+            M = h.shape[0]
+            if self.ref_cfg:
+                # unconditional rows (first half) ignore the bank (mutual_mix_attention.py:181-201)
+                begin = M // 2
+                b2 = bank.reshape(-1, C)
+                if brows == M:
+                    b2 = b2[begin:]
+                assert b2.shape[0] == M - begin, (b2.shape, M)
+            else:
+                begin, b2 = 0, bank.reshape(-1, C)
+                assert b2.shape[0] == M
+            n, kv = ops.layernorm(h, pk["n1w"], pk["n1b"], add=b2.contiguous(), add_mode=1, add_row_begin=begin)
+            q = ops.gemm(n, pk["q1"])
+            k = ops.gemm(kv, pk["k1"])
+            vt = ops.gemm(kv, pk["v1"], transpose_out=True)
+        else:
+            n = ops.layernorm(h, pk["n1w"], pk["n1b"])
+            if self.ref_mode == "write":
+                self.bank.append(n.view(B, L, C))
+                if self.stop_after_bank:
+                    return h
+            qk = ops.gemm(n, pk["qk1"])
+            q, k = qk[:, :C], qk[:, C:]
+            vt = ops.gemm(n, pk["v1"], transpose_out=True)
+        a = ops.attention(q, k, vt, B, H, D, L, L)
+        h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h)
+        # cross attention to the CLIP tokens
+        n2 = ops.layernorm(h, pk["n2w"], pk["n2b"])
+        q2 = ops.gemm(n2, pk["q2"])
+        kv2 = self._kv_cache.get(cross.key)
+        if kv2 is None:
+            self._kv_cache.clear()
+            kv2 = (ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True))
+            self._kv_cache[cross.key] = kv2
+        a2 = ops.attention(q2, kv2[0], kv2[1], B, H, D, L, cross.lk, kv_stride=cross.lpad, kv_index=cross.index)
+        h = ops.gemm(a2, pk["o2"], bias=pk["o2b"], residual=h)
+        n3 = ops.layernorm(h, pk["n3w"], pk["n3b"])
+        return _run_ff(pk, n3, h)
+
+
+class SpatialTransformer(_Packed):
+    """Transformer2DModel / Transformer3DModel: GroupNorm(eps 1e-6) -> 1x1 conv -> block -> 1x1 conv -> + residual
+    (reference src/models/transformer_2d.py:296-392, src/models/transformer_3d.py:106-205)."""
+
+    def __init__(self, c, ctx_dim, kind):
+        super().__init__()
+        self.c = c
+        self.norm = Affine(c)
+        self.proj_in = Conv(c, c, 1)
+        self.transformer_blocks = nn.ModuleList([TransformerBlock(c, ctx_dim, kind=kind)])
+        self.proj_out = Conv(c, c, 1)
+
+    def _pack(self, dev):
+        return dict(nw=packing.vec(self.norm.weight, dev), nb=packing.vec(self.norm.bias, dev),
+                    pi=packing.conv1x1_weight(self.proj_in.weight, dev), pib=packing.vec(self.proj_in.bias, dev),
+                    po=packing.conv1x1_weight(self.proj_out.weight, dev), pob=packing.vec(self.proj_out.bias, dev))
+
+    def forward(self, x, cross):
+        pk = self.packed()
+        B, Hh, Ww, C = x.shape
+        blk = self.transformer_blocks[0]
+        h = ops.groupnorm(x, pk["nw"], pk["nb"], GROUPS, 1e-6)
+        h = ops.gemm(tokens(h), pk["pi"], bias=pk["pib"])
+        h = blk(h, B, Hh * Ww, cross)
+        if blk.ref_mode == "write" and blk.stop_after_bank:
+            return x
+        return ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x)).view(x.shape)
+
+
+# ------------------------------------------------------------------------------------------------ motion module
+class _PositionalEncoding(nn.Module):
+    def __init__(self, dim, max_len):
+        super().__init__()
+        from .synth import positional_encoding_table
+        self.register_buffer("pe", positional_encoding_table(dim, max_len))
+
+
+class _TemporalAttention(Attention):
+    def __init__(self, dim, max_len):
+        super().__init__(dim)
+        self.pos_encoder = _PositionalEncoding(dim, max_len)
+
+
+class _TemporalBlock(nn.Module):
+    def __init__(self, dim, max_len):
+        super().__init__()
+        self.attention_blocks = nn.ModuleList([_TemporalAttention(dim, max_len), _TemporalAttention(dim, max_len)])
+        self.norms = nn.ModuleList([Affine(dim), Affine(dim)])
+        self.ff = FeedForward(dim)
+        self.ff_norm = Affine(dim)
+
+
+class _TemporalTransformer(nn.Module):
+    def __init__(self, dim, max_len):
+        super().__init__()
+        self.norm = Affine(dim)
+        self.proj_in = Linear(dim, dim)
+        self.transformer_blocks = nn.ModuleList([_TemporalBlock(dim, max_len)])
+        self.proj_out = Linear(dim, dim)
+
+
+class MotionModule(_Packed):
+    """VanillaTemporalModule (reference src/models/motion_module.py:45-272, 364-439): GroupNorm(1e-6) -> Linear ->
+    2 x [LayerNorm -> attention over frames (PE on the query input only) + res] -> LayerNorm -> GEGLU FF + res ->
+    Linear -> + residual."""
+
+    def __init__(self, dim, max_len=32, heads=HEADS):
+        super().__init__()
+        self.dim, self.heads, self.max_len = dim, heads, max_len
+        self.temporal_transformer = _TemporalTransformer(dim, max_len)
+
+    def _pack(self, dev):
+        L, V = packing.linear_weight, packing.vec
+        tt = self.temporal_transformer
+        tb = tt.transformer_blocks[0]
+        pk = dict(nw=V(tt.norm.weight, dev), nb=V(tt.norm.bias, dev), pi=L(tt.proj_in.weight, dev), pib=V(tt.proj_in.bias, dev),
+                  po=L(tt.proj_out.weight, dev), pob=V(tt.proj_out.bias, dev),
+                  fnw=V(tb.ff_norm.weight, dev), fnb=V(tb.ff_norm.bias, dev))
+        for i, (ab, nm) in enumerate(zip(tb.attention_blocks, tb.norms)):
+            pk[f"n{i}w"], pk[f"n{i}b"] = V(nm.weight, dev), V(nm.bias, dev)
+            pk[f"q{i}"] = L(ab.to_q.weight, dev)
+            pk[f"kv{i}"] = torch.cat([L(ab.to_k.weight, dev), L(ab.to_v.weight, dev)], 0).contiguous()
+            pk[f"o{i}"], pk[f"o{i}b"] = L(ab.to_out[0].weight, dev), V(ab.to_out[0].bias, dev)
+            pk[f"pe{i}"] = V(ab.pos_encoder.pe[0], dev)
+        _pack_ff(tb.ff, dev, pk)
+        return pk
+
+    def forward(self, x, nb, f):
+        """x: (nb*f, H, W, C), frames of one clip-half contiguous."""
+        pk = self.packed()
+        if f > self.max_len:
+            raise ValueError(f"window of {f} frames exceeds the positional-encoding table ({self.max_len})")
+        _, Hh, Ww, C = x.shape
+        HW, H = Hh * Ww, self.heads
+        h = ops.groupnorm(x, pk["nw"], pk["nb"], GROUPS, 1e-6)
+        h = ops.gemm(tokens(h), pk["pi"], bias=pk["pib"])
+        for i in range(2):
+            n, npe = ops.layernorm(h, pk[f"n{i}w"], pk[f"n{i}b"], add=pk[f"pe{i}"], add_mode=2, rows_per_frame=HW, frames=f)
+            q = ops.gemm(npe, pk[f"q{i}"])
+            kv = ops.gemm(n, pk[f"kv{i}"])
+            a = ops.temporal_attention(q, kv[:, :C], kv[:, C:], nb, f, HW, H, C // H)
+            h = ops.gemm(a, pk[f"o{i}"], bias=pk[f"o{i}b"], residual=h)
+        n = ops.layernorm(h, pk["fnw"], pk["fnb"])
+        h = _run_ff(pk, n, h)
+        return ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x)).view(x.shape)
+
+
+# ------------------------------------------------------------------------------------------------ MAN
+class MANModule(_Packed):
+    """Motion-Adaptive Normalization (reference src/models/man_module.py:7-33): InstanceNorm(x)*(1+gamma)+beta with
+    gamma/beta = 3x3 convs over relu(3x3 conv(nearest-resized 2-channel scene-motion map))."""
+
+    def __init__(self, norm_dim, m_dim=2):
+        super().__init__()
+        self.norm_dim, self.m_dim = norm_dim, m_dim
+        self.mlp_shared = nn.Sequential(Conv(m_dim, 128, 3), nn.ReLU())
+        self.mlp_gamma = Conv(128, norm_dim, 3)
+        self.mlp_beta = Conv(128, norm_dim, 3)
+
+    def _pack(self, dev):
+        gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
+        return dict(sh=packing.conv3x3_weight(self.mlp_shared[0].weight, dev), shb=packing.vec(self.mlp_shared[0].bias, dev),
+                    gb=packing.conv3x3_weight(gb, dev),
+                    gbb=packing.vec(torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0), dev))
+
+    def forward(self, x, motion_nhwc):
+        """motion_nhwc: (B, h', w', 64) fp16 -- the 2 flow channels nearest-resized to x's resolution, zero padded."""
+        pk = self.packed()
+        a = ops.conv3x3(motion_nhwc, pk["sh"], 128, bias=pk["shb"], act=ops.ACT_RELU)
+        gb = ops.conv3x3(a, pk["gb"], 2 * self.norm_dim, bias=pk["gbb"])
+        return ops.instnorm_spade(x, gb)
+
+
+# ------------------------------------------------------------------------------------------------ time embedding
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = Linear(cin, dim)
+        self.linear_2 = Linear(dim, dim)
+
+
+def timestep_sinusoid(t, dim):
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) -- fp32 on the host (a few hundred values)."""
+    import math
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    arg = torch.as_tensor(t, dtype=torch.float32).reshape(-1, 1) * freqs[None, :]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)

@@ -15,10 +15,12 @@ extern "C" const char* md_last_error(void) { return g_err; }
 extern "C" int md_version(void) { return 100; }
 
 // ---- strided gather -> NHWC fp16 with zero channel padding and optional nearest sub-sampling --------------------------
-// dst[n][y][x][c] = c < c_count ? src[(n / F)*sB + (n % F)*sF + (c_begin + c)*sC + (y*sub)*sY + (x*sub)*sX] : 0
+// dst[n][y][x][c] = c < c_count ? src[(n / F)*sB + (n % F)*sF + (c_begin + c)*sC + ny(y)*sY + nx(x)*sX] : 0
+// with ny(y) = min(floor(y * Hin / Ho), Hin - 1)  (PyTorch 'nearest' rule; identity when Hin == Ho)
 template <typename T>
 __global__ void pack_nhwc_kernel(const T* __restrict__ src, half_t* __restrict__ dst, long total, int F, long sB, long sF, long sC, long sY, long sX,
-                                 int c_begin, int c_count, int Cpad, int Ho, int Wo, int sub) {
+                                 int c_begin, int c_count, int Cpad, int Ho, int Wo, int Hin, int Win) {
+  const float fy = (float)Hin / (float)Ho, fx = (float)Win / (float)Wo;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int c = (int)(idx % Cpad);
     long r = idx / Cpad;
@@ -27,22 +29,25 @@ __global__ void pack_nhwc_kernel(const T* __restrict__ src, half_t* __restrict__
     const int y = (int)(r % Ho);
     const long n = r / Ho;
     float v = 0.f;
-    if (c < c_count) v = (float)src[(n / F) * sB + (n % F) * sF + (long)(c_begin + c) * sC + (long)(y * sub) * sY + (long)(x * sub) * sX];
+    if (c < c_count) {
+      const int sy = min((int)floorf(y * fy), Hin - 1), sx = min((int)floorf(x * fx), Win - 1);
+      v = (float)src[(n / F) * sB + (n % F) * sF + (long)(c_begin + c) * sC + (long)sy * sY + (long)sx * sX];
+    }
     dst[idx] = (half_t)v;
   }
 }
 
 extern "C" int md_pack_nhwc_f16(const void* src, int src_is_f32, void* dst, int N, int F, long sB, long sF, long sC, long sY, long sX, int c_begin,
-                                int c_count, int Cpad, int Ho, int Wo, int sub, void* stream) {
-  MD_CHECK_ARG(N > 0 && F > 0 && c_count <= Cpad && sub >= 1, "md_pack_nhwc: bad arguments");
+                                int c_count, int Cpad, int Ho, int Wo, int Hin, int Win, void* stream) {
+  MD_CHECK_ARG(N > 0 && F > 0 && c_count <= Cpad && Hin >= 1 && Win >= 1, "md_pack_nhwc: bad arguments");
   const long total = (long)N * Ho * Wo * Cpad;
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (src_is_f32)
     hipLaunchKernelGGL(pack_nhwc_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, (half_t*)dst, total, F, sB, sF, sC, sY, sX,
-                       c_begin, c_count, Cpad, Ho, Wo, sub);
+                       c_begin, c_count, Cpad, Ho, Wo, Hin, Win);
   else
     hipLaunchKernelGGL(pack_nhwc_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)src, (half_t*)dst, total, F, sB, sF, sC, sY, sX,
-                       c_begin, c_count, Cpad, Ho, Wo, sub);
+                       c_begin, c_count, Cpad, Ho, Wo, Hin, Win);
   MD_CHECK_LAUNCH("md_pack_nhwc");
   return MD_OK;
 }

@@ -148,14 +148,15 @@ def temporal_attention(q, k, v, NB, F, HW, H, D, out=None):
     return out
 
 
-def pack_nhwc(src, n, f, strides, c_begin, c_count, cpad, ho, wo, sub=1):
-    """Strided gather into a fresh (n, ho, wo, cpad) fp16 NHWC tensor.  strides = (sB, sF, sC, sY, sX) in elements."""
+def pack_nhwc(src, n, f, strides, c_begin, c_count, cpad, ho, wo, hin=None, win=None):
+    """Strided gather into a fresh (n, ho, wo, cpad) fp16 NHWC tensor.  strides = (sB, sF, sC, sY, sX) in elements.
+    (hin, win) != (ho, wo) applies PyTorch's nearest-neighbour resize rule."""
     if not src.is_cuda or src.dtype not in (torch.float16, torch.float32):
         raise _lib.MdanceHipError("pack_nhwc: source must be a CUDA fp16/fp32 tensor")
     dst = torch.empty((n, ho, wo, cpad), device=src.device, dtype=F16)
     sB, sF, sC, sY, sX = strides
     _lib.call("md_pack_nhwc_f16", src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(), n, f, sB, sF, sC, sY, sX,
-              c_begin, c_count, cpad, ho, wo, sub, _st())
+              c_begin, c_count, cpad, ho, wo, hin or ho, win or wo, _st())
     return dst
 
 

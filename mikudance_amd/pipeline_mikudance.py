@@ -1,0 +1,264 @@
+"""MikuDanceVideoPipeline -- API mirror of reference src/pipelines/pipeline_mikudance.py:36-704 whose denoising
+loop (:573-686) runs on the MI355X-native UNets / HIP kernels of this package.
+
+`__call__` keeps the reference signature and call order (CLIP embed -> VAE-encode every condition image -> 22-channel
+guidance tensor -> loop -> VAE decode).  The VAE and the CLIP vision tower are the caller's torch modules
+(`vae.encode(x).latent_dist.mean`, `vae.decode(z).sample`, `image_encoder(...)`) exactly as in the reference: they
+are per-clip constant cost outside the hot path ("next").  `denoise()` is the hot path itself on
+tensors and is what bench.py and the parity tests drive.
+
+Result-preserving reductions (proven identical on the CPU oracle in tests/test_oracle.py):
+  * the reference UNet's inputs and t == 0 are step-invariant -> it is evaluated ONCE per window, not once per step;
+  * only the conditional half of its banks is ever consumed -> it is evaluated on the f conditional frames only,
+    each with the context row the reference's `[u,c,u,c,...]` interleaving would have given it;
+  * the sample after its last bank write is discarded -> that tail is skipped;
+  * unconditional rows ignore the bank -> one attention pass with a per-row K/V source replaces two.
+`reference_reuse=False` restores the literal per-step evaluation (same results, for A/B timing).
+"""
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .context import get_context_scheduler
+from .mutual_mix_attention import ReferenceAttentionControl
+
+
+@dataclass
+class MikuDanceVideoPipelineOutput:
+    videos: Union[torch.Tensor, np.ndarray]
+
+
+def _pil_to_tensor(img, height, width, normalize):
+    """VaeImageProcessor(do_convert_rgb=True[, do_normalize]).preprocess for one PIL image -> (1,3,H,W) fp32."""
+    from PIL import Image
+    img = img.convert("RGB").resize((width, height), resample=Image.LANCZOS)
+    arr = torch.from_numpy(np.asarray(img).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    return arr * 2.0 - 1.0 if normalize else arr
+
+
+class MikuDanceVideoPipeline:
+    _optional_components = []
+    default_context_frames = 30
+
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, scheduler, image_proj_model=None, tokenizer=None,
+                 text_encoder=None, video_decoder=False):
+        self.vae, self.image_encoder = vae, image_encoder
+        self.reference_unet, self.denoising_unet, self.scheduler = reference_unet, denoising_unet, scheduler
+        self.image_proj_model, self.tokenizer, self.text_encoder = image_proj_model, tokenizer, text_encoder
+        self.video_decoder = video_decoder
+        self.vae_scale_factor = 8
+        self.reference_reuse = True
+        self._device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+    # ------------------------------------------------------------------------------------------ plumbing
+    def to(self, device=None, dtype=None):
+        for m in (self.vae, self.image_encoder, self.reference_unet, self.denoising_unet):
+            if m is not None and hasattr(m, "to"):
+                m.to(device=device, dtype=dtype) if dtype is not None else m.to(device)
+        if device is not None:
+            self._device = torch.device(device)
+        return self
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    def progress_bar(self, iterable=None, total=None):
+        from tqdm import tqdm
+        return tqdm(iterable, total=total, disable=getattr(self, "_progress_disabled", True))
+
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, video_length, dtype, device, generator,
+                        latents=None):
+        """reference :173-207 -- noise is drawn from the caller's generator on ITS device (CPU for the script's
+        torch.manual_seed generator, quirk 11), then moved."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            gdev = generator.device if generator is not None and not isinstance(generator, list) else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------------------------------ the hot path
+    @torch.no_grad()
+    def denoise(self, latents, ref_latents, image_prompt_embeds, num_inference_steps, guidance_scale, context_schedule="uniform",
+                context_frames=None, context_stride=1, context_overlap=8, callback=None, callback_steps=1):
+        """The loop of reference src/pipelines/pipeline_mikudance.py:573-686.
+
+        latents             (1, 4, F, h, w)  initial noise (any float dtype, on the GPU)
+        ref_latents         (1, F, 22, h, w) 20 VAE-latent guidance channels + 2 scene-motion channels
+        image_prompt_embeds (2, L, D) = [zeros, CLIP tokens] when guidance_scale > 1, else (1, L, D)
+        returns latents (1, 4, F, h, w) in the input dtype.
+        """
+        dev = latents.device
+        if dev.type != "cuda":
+            raise RuntimeError("MikuDanceVideoPipeline.denoise: tensors must live on the MI355X; there is no CPU path")
+        context_frames = context_frames or self.default_context_frames
+        do_cfg = guidance_scale > 1.0
+        nb = 2 if do_cfg else 1
+        den, refu, sch = self.denoising_unet, self.reference_unet, self.scheduler
+        sch.set_timesteps(num_inference_steps)
+        timesteps = [int(t) for t in sch.timesteps]
+        _, c, F_, hh, ww = latents.shape
+        HW = hh * ww
+        writer = ReferenceAttentionControl(refu, do_classifier_free_guidance=do_cfg, mode="write", batch_size=1, fusion_blocks="full")
+        reader = ReferenceAttentionControl(den, do_classifier_free_guidance=do_cfg, mode="read", batch_size=1, fusion_blocks="full")
+        reader_blocks = reader._blocks(den)
+
+        # internal latents: (F, h, w, 4) fp16 NHWC frames
+        st = latents.stride()
+        lat = ops.pack_nhwc(latents, F_, F_, (0, st[2], st[1], st[3], st[4]), 0, c, 4, hh, ww)
+        noise_sum = torch.zeros((nb, F_, HW, 4), device=dev, dtype=torch.float32)
+        counter = torch.zeros((F_,), device=dev, dtype=torch.float32)
+        windows = [list(w) for w in get_context_scheduler(context_schedule)(0, num_inference_steps, F_, context_frames,
+                                                                            context_stride, context_overlap)]
+        win_dev = [torch.tensor(w, dtype=torch.int32, device=dev) for w in windows]
+        win_long = [w.long() for w in win_dev]
+        whole = len(windows) == 1 and windows[0] == list(range(F_))
+        embeds = image_prompt_embeds
+        bank_cache = {}
+        refu.skip_dead_tail = True
+        try:
+            for step_i, t in enumerate(timesteps):
+                noise_sum.zero_()
+                counter.zero_()
+                for wi, win in enumerate(windows):
+                    f = len(win)
+                    # ---- reference UNet (write): once per window unless reference_reuse is off
+                    if wi not in bank_cache or not self.reference_reuse:
+                        self._write_banks(writer, reader, embeds, ref_latents, win_long[wi], f, do_cfg, literal=not self.reference_reuse)
+                        banks = [blk.bank for blk in reader_blocks]
+                        if self.reference_reuse:
+                            bank_cache[wi] = banks
+                    else:
+                        for blk, bk in zip(reader_blocks, bank_cache[wi]):
+                            blk.bank = bk
+                    # ---- denoising UNet (read)
+                    src = lat if whole else lat.index_select(0, win_long[wi])
+                    x = ops.pack_nhwc(src, nb * f, f, (0, HW * 4, 1, ww * 4, 4), 0, 4, 64, hh, ww)
+                    cross = den._cross(embeds[:nb], [i // f for i in range(nb * f)], dev)
+                    pred = den.forward_nhwc(x, nb, f, torch.full((nb,), float(t)), cross)
+                    ops.window_accumulate(pred, noise_sum, counter, win_dev[wi], f, F_, HW, halves=nb)
+                    reader.clear()
+                    writer.clear()
+                a_t, a_prev = sch.step_coefficients(t)
+                ops.cfg_ddim_step(lat, noise_sum, counter, F_, HW, guidance_scale, a_t, a_prev, halves=nb)
+                if callback is not None and step_i % callback_steps == 0:
+                    callback(step_i, t, self._latents_out(lat, latents))
+        finally:
+            refu.skip_dead_tail = False
+            reader.clear()
+            writer.clear()
+        return self._latents_out(lat, latents)
+
+    def _latents_out(self, lat, like):
+        out = torch.empty(like.shape, device=like.device, dtype=like.dtype)
+        _, c, F_, hh, ww = like.shape
+        so = out.stride()
+        ops.unpack_nhwc(lat, out, F_, F_, (0, so[2], so[1], so[3], so[4]), c, hh, ww)
+        return out
+
+    def _write_banks(self, writer, reader, embeds, ref_latents, win_long, f, do_cfg, literal):
+        """Run the reference UNet in write mode for one window and hand its banks to the reader blocks."""
+        refu = self.reference_unet
+        dev = ref_latents.device
+        g = ref_latents[0].index_select(0, win_long)                         # (f, 22, h, w)
+        if literal and do_cfg:
+            g = g.repeat(2, 1, 1, 1)                                         # [uncond f | cond f] (:636-643)
+            index = [k % 2 for k in range(2 * f)]                            # embeds.repeat((f,1,1)) = [u,c,u,c,...] (:645)
+        elif do_cfg:
+            index = [(f + j) % 2 for j in range(f)]                          # what cond frame j sees under that interleaving
+        else:
+            index = [0] * f
+        B, nch, hh, ww = g.shape
+        st = g.stride()
+        x = ops.pack_nhwc(g, B, 1, (st[0], 0, st[1], st[2], st[3]), 0, nch - 2, 64, hh, ww)
+
+        def motion_at(h2, w2):
+            return ops.pack_nhwc(g, B, 1, (st[0], 0, st[1], st[2], st[3]), nch - 2, 2, 64, h2, w2, hin=hh, win=ww)
+
+        cross = refu._cross(embeds, index, dev)
+        refu.forward_nhwc(x, motion_at, cross)
+        reader.update(writer)
+
+    # ------------------------------------------------------------------------------------------ VAE glue (caller's modules)
+    def _encode(self, tensor):
+        return self.vae.encode(tensor.to(dtype=self.vae.dtype, device=self.vae.device)).latent_dist.mean * 0.18215
+
+    def decode_latents(self, latents):
+        """reference :115-130 -- per-frame VAE decode, (x/2+0.5).clamp(0,1), float32 numpy (b,c,f,h,w)."""
+        video_length = latents.shape[2]
+        latents = 1 / 0.18215 * latents
+        latents = latents.permute(0, 2, 1, 3, 4).reshape((-1,) + tuple(latents.shape[1:2]) + tuple(latents.shape[3:]))
+        video = [self.vae.decode(latents[i:i + 1].to(self.vae.dtype)).sample for i in range(latents.shape[0])]
+        video = torch.cat(video)
+        video = video.reshape((-1, video_length) + tuple(video.shape[1:])).permute(0, 2, 1, 3, 4)
+        video = (video / 2 + 0.5).clamp(0, 1)
+        return video.cpu().float().numpy()
+
+    def decode_temporal(self, latents, decode_chunk_size=16):
+        """reference :132-150 (AutoencoderKLTemporalDecoder in chunks of 16)."""
+        video_length = latents.shape[2]
+        latents = 1 / 0.18215 * latents
+        latents = latents.permute(0, 2, 1, 3, 4).reshape((-1,) + tuple(latents.shape[1:2]) + tuple(latents.shape[3:]))
+        video = []
+        for i in range(0, latents.shape[0], decode_chunk_size):
+            chunk = latents[i:i + decode_chunk_size]
+            video.append(self.vae.decode(chunk.to(self.vae.dtype), num_frames=chunk.shape[0]).sample)
+        video = torch.cat(video)
+        video = video.reshape((-1, video_length) + tuple(video.shape[1:])).permute(0, 2, 1, 3, 4)
+        video = (video / 2 + 0.5).clamp(0, 1)
+        return video.cpu().float().numpy()
+
+    def clip_embeds(self, ref_image):
+        """reference :406-416 -- all 257 tokens: last_hidden_state -> post_layernorm -> visual_projection."""
+        from transformers import CLIPImageProcessor
+        clip_image = CLIPImageProcessor().preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+        enc = self.image_encoder
+        emb = enc(clip_image.to(self._device, dtype=enc.dtype)).last_hidden_state
+        return enc.visual_projection(enc.vision_model.post_layernorm(emb))
+
+    # ------------------------------------------------------------------------------------------ reference-compatible call
+    @torch.no_grad()
+    def __call__(self, ref_image, ref_skel_image, tgt_pose_images, tgt_face_images, tgt_hand_images, scene_motion_npy, width,
+                 height, video_length, num_inference_steps, guidance_scale, num_images_per_prompt=1, eta: float = 0.0,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None, output_type: Optional[str] = "tensor",
+                 return_dict: bool = True, callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
+                 callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=None, context_stride=1,
+                 context_overlap=8, context_batch_size=1, interpolation_factor=1, **kwargs):
+        if eta != 0.0 or context_batch_size != 1 or interpolation_factor != 1:
+            raise NotImplementedError("eta != 0, context_batch_size != 1 and interpolation_factor != 1 are never used by "
+                                      "scripts/inference_video.py (SURVEY.md component 3b)")
+        height = height or 768
+        width = width or 768
+        device = self._execution_device
+        do_cfg = guidance_scale > 1.0
+        batch_size = 1
+        image_prompt_embeds = self.clip_embeds(ref_image)
+        if do_cfg:
+            image_prompt_embeds = torch.cat([torch.zeros_like(image_prompt_embeds), image_prompt_embeds], dim=0)
+        latents = self.prepare_latents(batch_size * num_images_per_prompt, self.denoising_unet.in_channels, width, height,
+                                       video_length, image_prompt_embeds.dtype, device, generator)
+        f = video_length
+        rep = lambda z: z.unsqueeze(1).repeat(1, f, 1, 1, 1).reshape((-1,) + tuple(z.shape[1:]))
+        ref_image_latents = rep(self._encode(_pil_to_tensor(ref_image, height, width, True)))
+        pose_ref_latents = rep(self._encode(_pil_to_tensor(ref_skel_image, height, width, False)))
+        per_frame = lambda imgs: torch.cat([self._encode(_pil_to_tensor(im, height, width, False)) for im in imgs], dim=0)
+        pose_tgt, face_tgt, hand_tgt = per_frame(tgt_pose_images), per_frame(tgt_face_images), per_frame(tgt_hand_images)
+        tracker = torch.from_numpy(np.asarray(scene_motion_npy)).to(dtype=ref_image_latents.dtype, device=ref_image_latents.device)
+        ref_latents = torch.cat([ref_image_latents, pose_ref_latents, pose_tgt, face_tgt, hand_tgt, tracker], dim=1)[None]
+        latents = self.denoise(latents, ref_latents, image_prompt_embeds, num_inference_steps, guidance_scale, context_schedule,
+                               context_frames, context_stride, context_overlap, callback, callback_steps)
+        images = self.decode_temporal(latents) if self.video_decoder else self.decode_latents(latents)
+        if output_type == "tensor":
+            images = torch.from_numpy(images)
+        if not return_dict:
+            return images
+        return MikuDanceVideoPipelineOutput(videos=images)

@@ -1,0 +1,61 @@
+"""smoke(): one tiny invocation of the hot path on cuda:0 (reduced-width UNets, 16x16 latents, 4 frames, 2 DDIM steps),
+checked against the CPU oracle.  The oracle is used here ONLY as the checker (see oracle/cpu_ref.py header)."""
+import json
+import os
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = dict(block_out_channels=(64, 128, 256, 256), cross_attention_dim=64)
+MM_KWARGS = dict(use_inflated_groupnorm=True, unet_use_cross_frame_attention=False, unet_use_temporal_attention=False,
+                 use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=True,
+                 motion_module_decoder_only=False, motion_module_type="Vanilla",
+                 motion_module_kwargs=dict(num_attention_heads=8, num_transformer_block=1,
+                                           attention_block_types=["Temporal_Self", "Temporal_Self"],
+                                           temporal_position_encoding=True, temporal_position_encoding_max_len=32,
+                                           temporal_attention_dim_div=1))
+SCHED_KWARGS = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                    prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+
+
+def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device="cuda", dtype=torch.float16):
+    """Both UNets with seeded synthetic weights (no checkpoints exist offline).  Returns (ref, den, ref_sd, den_sd)."""
+    from . import UNet2DConditionModel, UNet3DConditionModel
+    from .synth import synth_state_dict
+    geom = dict(SMALL if geom is None else geom)
+    den = UNet3DConditionModel(sample_size=16, **geom, **MM_KWARGS)
+    ref = UNet2DConditionModel(sample_size=16, **geom)
+    den_sd = synth_state_dict({k: tuple(v.shape) for k, v in den.state_dict().items()}, seed=seed_den, mode=mode)
+    ref_sd = synth_state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, seed=seed_ref, mode=mode)
+    den.load_state_dict(den_sd, strict=True)
+    ref.load_state_dict(ref_sd, strict=True)
+    return ref.to(device=device, dtype=dtype), den.to(device=device, dtype=dtype), ref_sd, den_sd
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def cosine(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def smoke():
+    assert torch.cuda.is_available(), "smoke() needs cuda:0"
+    from . import DDIMScheduler, MikuDanceVideoPipeline, _lib
+    from .synth import synth_inputs
+    _lib.load()
+    torch.cuda.set_device(0)
+    ref, den, ref_sd, den_sd = build_models()
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    latents, ref_latents, embeds = synth_inputs(4, 16, 16, ctx_len=5, ctx_dim=64, seed=100)
+    out = pipe.denoise(latents.cuda().half(), ref_latents.cuda().half(), embeds.cuda().half(), 2, 3.5)
+    torch.cuda.synchronize()
+    from oracle import cpu_ref as O                                   # checker only
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, latents, ref_latents, embeds, 2, guidance_scale=3.5, reduced=True)
+    r, c = rel_l2(out.float(), want), cosine(out.float(), want)
+    print(json.dumps({"smoke": "denoise 2 steps, 4 frames, 16x16 latents, reduced-width UNets", "rel_l2": r, "cosine": c}))
+    assert r < 3e-2 and c > 0.999, (r, c)

@@ -1,0 +1,64 @@
+"""CPU: host-side logic of the product package (no kernels): state-dict key layout vs the reference, window
+scheduler, DDIM table, config handling."""
+import json
+import os
+
+import pytest
+import torch
+
+import mikudance_amd as M
+from mikudance_amd.selftest import MM_KWARGS, SCHED_KWARGS, SMALL
+from oracle import cpu_ref as O
+
+
+@pytest.mark.parametrize("name,geom", [("", {}), ("_small", SMALL)])
+def test_state_dict_keys_match_reference(golden_dir, name, geom):
+    gold = json.load(open(os.path.join(golden_dir, f"g6_state_dict_keys{name}.json")))
+    with torch.device("meta"):
+        den = M.UNet3DConditionModel(sample_size=16, **geom, **MM_KWARGS)
+        ref = M.UNet2DConditionModel(sample_size=16, **geom)
+    for m, g in ((den, gold["denoising_unet"]), (ref, gold["reference_unet"])):
+        sd = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert sd == g
+
+
+def test_windows_match_reference(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "g1_windows.json"))):
+        got = list(M.get_context_scheduler("uniform")(0, case["steps"], case["num_frames"], case["context_frames"], 1, case["overlap"]))
+        assert got == case["windows"]
+    with pytest.raises(ValueError):
+        M.get_context_scheduler("nope")
+
+
+def test_ddim_table_matches_oracle():
+    s, o = M.DDIMScheduler(**SCHED_KWARGS), O.DDIM()
+    assert torch.equal(s.alphas_cumprod, o.alphas_cumprod)
+    for n in (4, 20, 30):
+        s.set_timesteps(n); o.set_timesteps(n)
+        assert torch.equal(s.timesteps, o.timesteps)
+        for t in s.timesteps:
+            assert s.step_coefficients(t) == o.coeffs(t)
+    with pytest.raises(NotImplementedError):
+        M.DDIMScheduler()                       # epsilon / leading defaults are not the MikuDance configuration
+
+
+def test_reference_control_pairs_blocks_like_the_reference():
+    with torch.device("meta"):
+        den = M.UNet3DConditionModel(sample_size=16, **SMALL, **MM_KWARGS)
+        ref = M.UNet2DConditionModel(sample_size=16, **SMALL)
+    w = M.ReferenceAttentionControl(ref, mode="write", fusion_blocks="full")
+    r = M.ReferenceAttentionControl(den, mode="read", do_classifier_free_guidance=True, fusion_blocks="full")
+    names_r = {id(m): n for n, m in den.named_modules()}
+    names_w = {id(m): n for n, m in ref.named_modules()}
+    pr = [names_r[id(b)] for b in r._blocks(den)]
+    pw = [names_w[id(b)] for b in w._blocks(ref)]
+    assert pr == pw and len(pr) == 16
+    assert [b.dim for b in r._blocks(den)] == [256] * 6 + [128] * 5 + [64] * 5
+    assert pr[0].startswith("down_blocks.2") and pr[5].startswith("mid_block")
+
+
+def test_unsupported_configs_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        M.UNet3DConditionModel(use_linear_projection=True)
+    with pytest.raises(RuntimeError):
+        M.UNet3DConditionModel.from_pretrained_2d("/nonexistent", "/nonexistent.pth")

@@ -248,8 +248,11 @@ def test_pack_unpack_concat(dev):
     # channel sub-range + nearest sub-sampling (motion map of MAN)
     m = torch.randn(5, 22, 16, 16, generator=torch.Generator().manual_seed(61)).half().to(dev)
     st = m.stride()
-    pm = ops.pack_nhwc(m, 5, 1, (st[0], 0, st[1], st[2], st[3]), 20, 2, 64, 4, 4, sub=4)
+    pm = ops.pack_nhwc(m, 5, 1, (st[0], 0, st[1], st[2], st[3]), 20, 2, 64, 4, 4, hin=16, win=16)
     refm = F.interpolate(m[:, 20:].float().cpu(), size=(4, 4), mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(pm.cpu().float()[..., :2], refm)
+    pm = ops.pack_nhwc(m, 5, 1, (st[0], 0, st[1], st[2], st[3]), 20, 2, 64, 5, 3, hin=16, win=16)
+    refm = F.interpolate(m[:, 20:].float().cpu(), size=(5, 3), mode="nearest").permute(0, 2, 3, 1)
     assert torch.equal(pm.cpu().float()[..., :2], refm)
     assert pm[..., 2:].abs().max().item() == 0
     # unpack back to NCFHW fp32

@@ -1,0 +1,103 @@
+"""GPU: the MI355X-native UNets and the denoising loop (through the C ABI) against
+  (a) the golden vectors generated from the reference (tests/golden/g4_g5_*), and
+  (b) the CPU oracle on the same seeded inputs.
+Stated tolerances: fp16 HIP path vs fp32 reference/oracle: relative L2 <= 3e-2 and cosine >= 0.999;
+banks (a LayerNorm output, O(1) values): |err| <= 2e-2 * maxabs + 2e-3."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+pytestmark = pytest.mark.gpu
+
+from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline, ReferenceAttentionControl  # noqa: E402
+from mikudance_amd.selftest import SCHED_KWARGS, build_models, cosine, rel_l2  # noqa: E402
+from oracle import cpu_ref as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    assert torch.cuda.is_available()
+    meta = json.load(open(os.path.join(golden_dir, "g4_g5_meta.json")))
+    ref, den, ref_sd, den_sd = build_models(seed_den=meta["seed_den"], seed_ref=meta["seed_ref"])
+    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
+    t = load_file(os.path.join(golden_dir, "g4_g5_unets.safetensors"))
+    return meta, ref, den, ref_sd, den_sd, t
+
+
+def test_g4_unets_literal_call_pattern(small):
+    """The reference's own call pattern (pipeline_mikudance.py:626-660) through the API-compatible forward()s."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    dev = "cuda"
+    latents, ref_latents, embeds = (t[k].to(dev).half() for k in ("in.latents", "in.ref_latents", "in.embeds"))
+    win, f = [0, 1, 2, 3], 4
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
+    g = ref_latents[:, win].repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, 16, 16)
+    emb_in = embeds.repeat((f, 1, 1))
+    ref_out = ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)[0]
+    assert rel_l2(ref_out[f:].float(), t["g4.ref_out_cond"]) < 3e-2
+    reader.update(writer)
+    names = {id(m): n for n, m in den.named_modules()}
+    n = 0
+    for blk in reader._blocks(den):
+        gold = t["bank." + names[id(blk)]].float()
+        got = blk.bank[0][f:].float().cpu()
+        assert got.shape == gold.shape
+        err = (got - gold).abs().max().item()
+        assert err <= 2e-2 * gold.abs().max().item() + 2e-3, (names[id(blk)], err)
+        n += 1
+    assert n == 16
+    x = latents[:, :, win].repeat(2, 1, 1, 1, 1)
+    pred = den(x, torch.tensor(601), encoder_hidden_states=emb_in[:2], return_dict=False)[0]
+    reader.clear(); writer.clear()
+    r, c = rel_l2(pred.float(), t["g4.pred"]), cosine(pred.float(), t["g4.pred"])
+    assert r < 3e-2 and c > 0.999, (r, c)
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_g5_loop_vs_reference_golden(small, reuse):
+    meta, ref, den, ref_sd, den_sd, t = small
+    g5 = meta["g5"]
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    pipe.reference_reuse = reuse
+    snaps = {}
+    out = pipe.denoise(t["in.latents"].cuda().half(), t["in.ref_latents"].cuda().half(), t["in.embeds"].cuda().half(), g5["steps"],
+                       g5["guidance"], context_frames=g5["context_frames"], context_stride=1, context_overlap=g5["overlap"],
+                       callback=lambda i, ts, lat: snaps.__setitem__(ts, lat.float().cpu()))
+    for ts in g5["timesteps"]:
+        gold = t[f"g5.latents_after_t{ts}"]
+        r, c = rel_l2(snaps[ts], gold), cosine(snaps[ts], gold)
+        assert r < 3e-2 and c > 0.999, (ts, r, c)
+    last = t[f"g5.latents_after_t{g5['timesteps'][-1]}"]
+    assert rel_l2(out.float(), last) < 3e-2
+
+
+def test_loop_no_cfg_and_single_window_vs_oracle(small):
+    meta, ref, den, ref_sd, den_sd, t = small
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    lat, rl, emb = t["in.latents"][:, :, :4], t["in.ref_latents"][:, :4], t["in.embeds"]
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 3, guidance_scale=3.5, reduced=True)
+    out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 3, 3.5)
+    assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+
+
+def test_scheduler_step_api(small):
+    sch = DDIMScheduler(**SCHED_KWARGS)
+    sch.set_timesteps(20)
+    o = O.DDIM(); o.set_timesteps(20)
+    x, v = torch.randn(1, 4, 3, 8, 8), torch.randn(1, 4, 3, 8, 8)
+    got = sch.step(v.cuda(), 949, x.cuda()).prev_sample
+    assert rel_l2(got.float(), o.step(v, 949, x)) < 2e-3
+
+
+def test_run_to_run_bitwise_determinism(small):
+    meta, ref, den, ref_sd, den_sd, t = small
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    args = (t["in.latents"][:, :, :4].cuda().half(), t["in.ref_latents"][:, :4].cuda().half(), t["in.embeds"].cuda().half(), 2, 3.5)
+    a, b = pipe.denoise(*args), pipe.denoise(*args)
+    assert torch.equal(a, b)
