@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py -- MikuDance denoising loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic input: the full denoising loop (20 DDIM steps,
+reference_unet + denoising_unet + motion modules + CFG + DDIM) of ONE 768x768x16-frame clip per GPU (BASELINE.json
+configs[1]; weak scaling: every added GPU brings its own clip, configs[3]).  Inputs are resident in HBM when the timed
+region starts (rank 0 scatters the per-clip conditioning over RCCL inside the region when N > 1, and gathers the final
+latents).  value = frames of all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel of the timed region: algorithmic FLOPs per launch / average launch duration measured with
+               HIP events on the launch stream, against the dense fp16 MFMA peak (2.5 PFLOP/s)
+  cpu_baseline the CPU oracle (a port of the reference's PyTorch path, oracle/cpu_ref.py) timed on this host's cores on a
+               bounded sample: ONE DDIM step of ONE frame at 768x768 with the full-width UNets, literal reference algorithm
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16 = 2.5e15
+PEAK_HBM = 8.0e12
+FULL = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=768)
+    ap.add_argument("--ddim-steps", type=int, default=20)
+    ap.add_argument("--guidance", type=float, default=3.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reuse", action="store_true", help="literal reference algorithm: reference UNet at every step on 2f frames")
+    ap.add_argument("--small", action="store_true", help="reduced-width UNets (debug only; NOT the benchmark)")
+    args = ap.parse_args()
+
+    from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline, _lib, dp
+    from mikudance_amd.selftest import SCHED_KWARGS, build_models
+    from mikudance_amd.synth import synth_inputs
+
+    rank, world = dp.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    _lib.load()
+
+    geom = None if args.small else FULL
+    ctx = (5, 64) if args.small else (257, 768)
+    t0 = time.time()
+    ref, den, ref_sd, den_sd = build_models(geom=geom, device=dev)
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    pipe.reference_reuse = not args.no_reuse
+    h = w = args.size // 8
+    setup_s = time.time() - t0
+
+    def make_clip(seed):
+        lat, rl, emb = synth_inputs(args.frames, h, w, ctx_len=ctx[0], ctx_dim=ctx[1], seed=seed)
+        return lat.half(), rl.half(), emb.half()
+
+    def one_step(step_idx):
+        # rank 0 owns the batch: scatter the per-clip conditioning, every rank denoises its clip, gather the latents
+        clips = [tuple(t.to(dev) for t in make_clip(100 + r)) for r in range(world)] if rank == 0 else None
+        return clips
+
+    # inputs resident in HBM before the timed region
+    staged = one_step(0)
+
+    def run(clips):
+        lat, rl, emb = dp.scatter_clips(clips, dev)
+        out = pipe.denoise(lat, rl, emb, args.ddim_steps, args.guidance)
+        return dp.gather_latents(out)
+
+    for _ in range(args.warmup):
+        res = run(staged)
+    torch.cuda.synchronize()
+    dp.barrier()
+    _lib.PROFILER.start()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = run(staged)
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.PROFILER.stop()
+    elapsed = dp.max_over_ranks(elapsed, dev)
+
+    if rank != 0:
+        return
+    assert all(torch.isfinite(r.float()).all() for r in res), "non-finite latents"
+    prof = _lib.PROFILER.summary()
+    total_flops = sum(d["flops"] for d in prof.values()) / max(args.steps, 1)
+    kernel_ms = sum(d["ms"] for d in prof.values()) / max(args.steps, 1)
+
+    def family(label):
+        return label.split(" ")[0] + (" D=" + label.split("D=")[1].split(" ")[0] if label.startswith("attention") else "")
+    fam = {}
+    for label, d in prof.items():
+        f = fam.setdefault(family(label), dict(ms=0.0, flops=0.0, count=0, bytes=0.0))
+        for k in ("ms", "flops", "count", "bytes"):
+            f[k] += d[k]
+    dom_label, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    dom_flops_per_launch = dom["flops"] / dom["count"]
+    dom_ms = dom["ms"] / dom["count"]
+    if dom_flops_per_launch > 0:
+        achieved = dom_flops_per_launch / (dom_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom_label, achieved=achieved, peak=PEAK_MFMA_F16 / 1e12, unit="TFLOP/s",
+                        frac=achieved / (PEAK_MFMA_F16 / 1e12), launches=dom["count"], avg_ms=dom_ms, traffic=None)
+    else:
+        achieved = dom["bytes"] / dom["count"] / (dom_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=dom_label, achieved=achieved, peak=PEAK_HBM / 1e9, unit="GB/s",
+                        frac=achieved / (PEAK_HBM / 1e9), launches=dom["count"], avg_ms=dom_ms, traffic=None)
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        roofline["traffic"] = json.load(open(pmc)).get(dom_label.split(" ")[0])
+
+    frames_total = args.frames * args.steps * world
+    value = frames_total / elapsed
+    line = {
+        "metric": "frames/sec (768x768, 16f, 20 DDIM steps)", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {args.size}x{args.size}, {args.frames}-frame clip, {args.ddim_steps} DDIM steps, fp16, "
+                               "reference_unet + denoising_unet + motion_module, CFG 3.5, one clip per GPU per step",
+                   "parallelism": f"dp{world}", "reference_reuse": pipe.reference_reuse, "weights": "random-init SD-1.5 geometry "
+                   "(N(0,1/fan_in), seeds 1234/4321)", "width": "reduced(debug)" if args.small else "full"},
+        "executed_tflop_per_clip": total_flops / 1e12, "mfma_frac_whole_loop": total_flops / (elapsed / args.steps) / PEAK_MFMA_F16,
+        "kernel_ms_per_clip": kernel_ms, "setup_s": setup_s,
+        "kernel_families": {k: dict(ms_per_clip=v["ms"] / args.steps, tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                                    gbps=(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if not v["flops"] else None,
+                                    launches=v["count"] // args.steps) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+        "roofline": roofline,
+    }
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]
+    line["top_launch_shapes"] = [dict(label=k, ms_per_clip=v["ms"] / args.steps, launches=v["count"] // args.steps,
+                                      tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None) for k, v in top]
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(ref_sd, den_sd, args, ctx)
+    print(json.dumps(line))
+
+
+def cpu_baseline(ref_sd, den_sd, args, ctx):
+    """The CPU oracle (port of the reference's PyTorch path) on a bounded sample: ONE DDIM step of ONE frame at the
+    benchmark resolution, literal reference algorithm (reference UNet on [uncond|cond] + denoising UNet on [uncond|cond])."""
+    from oracle import cpu_ref as O                                     # cpu_baseline leg only
+    from mikudance_amd.synth import synth_inputs
+    h = w = args.size // 8
+    lat, rl, emb = synth_inputs(1, h, w, ctx_len=ctx[0], ctx_dim=ctx[1], seed=100)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        g = rl[:, [0]].repeat(2, 1, 1, 1, 1).reshape(2, 22, h, w)
+        banks, _ = O.reference_unet_forward(ref_sd, g, emb.repeat((1, 1, 1)))
+        banks = {k: v.half().float() for k, v in banks.items()}
+        O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(999), emb, banks, cfg=True)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * args.ddim_steps), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 DDIM step of 1 frame at {args.size}x{args.size} (reference_unet + denoising_unet, CFG pair, fp32, "
+                      f"full-width random-init weights) = {dt:.1f} s; frames/s = 1 / ({args.ddim_steps} steps x that)"}
+
+
+if __name__ == "__main__":
+    main()

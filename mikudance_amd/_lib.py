@@ -58,8 +58,46 @@ def load():
     return _lib
 
 
-def call(name, *args):
+class Profiler:
+    """Optional per-launch HIP-event timing (bench.py): each C-ABI call is bracketed by two events recorded on the
+    stream the kernel is enqueued on (torch's current stream), tagged with its algorithmic FLOPs / bytes."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def start(self):
+        self.records = []
+        self.enabled = True
+
+    def stop(self):
+        self.enabled = False
+
+    def summary(self):
+        """label -> dict(count, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for label, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(label, dict(count=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["count"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILER = Profiler()
+
+
+def call(name, *args, meta=None):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if PROFILER.enabled and meta is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        PROFILER.records.append((meta[0], meta[1], meta[2], e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise MdanceHipError(f"{name} failed ({rc}): {lib.md_last_error().decode()}")

@@ -51,7 +51,9 @@ def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
     _chk(bias, "bias")
     _lib.call("md_gemm_f16", a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias), _p(residual), ldr,
-              _p(rowadd), ldra, rows_per_group, act, int(transpose_out), _st())
+              _p(rowadd), ldra, rows_per_group, act, int(transpose_out), _st(),
+              meta=(f"gemm M={M} N={N} K={K}" + (" geglu" if act == ACT_GEGLU else "") + (" T" if transpose_out else ""),
+                    2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
     return out
 
 
@@ -74,7 +76,9 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
     _chk(bias, "bias")
     _lib.call("md_conv3x3_nhwc_f16", x.data_ptr(), w.data_ptr(), out.data_ptr(), ldy, B, H, W, Cin, cout, stride,
-              int(upsample), _p(bias), _p(r2), ldr, _p(rowadd), ldra, rows_per_group, act, _st())
+              int(upsample), _p(bias), _p(r2), ldr, _p(rowadd), ldra, rows_per_group, act, _st(),
+              meta=(f"conv3x3 B={B} {H}x{W} Cin={Cin} Cout={cout} s={stride} up={int(upsample)}",
+                    2.0 * B * Ho * Wo * cout * 9 * Cin, 2.0 * (B * H * W * Cin + cout * 9 * Cin + B * Ho * Wo * cout)))
     return out
 
 
@@ -96,7 +100,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, out=None):
     if out is None:
         out = torch.empty_like(x)
     _lib.call("md_groupnorm_nhwc_f16", x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, C, groups,
-              float(eps), int(silu), ws.data_ptr(), ws.numel() * 4, _st())
+              float(eps), int(silu), ws.data_ptr(), ws.numel() * 4, _st(),
+              meta=(f"groupnorm B={B} HW={HW} C={C}", 0.0, 6.0 * B * HW * C))
     return out
 
 
@@ -108,7 +113,8 @@ def layernorm(x, gamma, beta, eps=1e-5, add=None, add_mode=0, add_row_begin=0, r
     y = torch.empty_like(x)
     y2 = torch.empty_like(x) if add_mode else None
     _lib.call("md_layernorm_f16", x.data_ptr(), y.data_ptr(), _p(y2), gamma.data_ptr(), beta.data_ptr(), _p(add), M, C,
-              float(eps), add_mode, add_row_begin, rows_per_frame, frames, _st())
+              float(eps), add_mode, add_row_begin, rows_per_frame, frames, _st(),
+              meta=(f"layernorm M={M} C={C} mode={add_mode}", 0.0, 2.0 * M * C * (2 + (2 if add_mode else 0))))
     return (y, y2) if add_mode else y
 
 
@@ -133,7 +139,8 @@ def attention(q, k, vt, B, H, D, Lq, Lk, kv_stride=None, kv_index=None, scale=No
     ldo = _rowmajor(out, "out")
     _lib.call("md_attention_fwd_f16", q.data_ptr(), ldq, k.data_ptr(), ldk, vt.data_ptr(), ldvt, out.data_ptr(), ldo,
               _p(kv_index), B, H, D, Lq, Lk, kv_stride if kv_stride is not None else Lk,
-              float(scale if scale is not None else D ** -0.5), _st())
+              float(scale if scale is not None else D ** -0.5), _st(),
+              meta=(f"attention B={B} H={H} D={D} Lq={Lq} Lk={Lk}", 4.0 * B * H * Lq * Lk * D, 2.0 * B * H * D * (2 * Lq + 2 * Lk)))
     return out
 
 
@@ -144,7 +151,8 @@ def temporal_attention(q, k, v, NB, F, HW, H, D, out=None):
         out = torch.empty((NB * F * HW, H * D), device=q.device, dtype=F16)
     ldo = _rowmajor(out, "out")
     _lib.call("md_temporal_attention_fwd_f16", q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(), ldo,
-              NB, F, HW, H, D, float(D ** -0.5), _st())
+              NB, F, HW, H, D, float(D ** -0.5), _st(),
+              meta=(f"temporal_attention NB={NB} F={F} HW={HW} D={D}", 4.0 * NB * HW * H * F * F * D, 8.0 * NB * F * HW * H * D))
     return out
 
 
