@@ -62,3 +62,13 @@ def test_unsupported_configs_fail_loudly():
         M.UNet3DConditionModel(use_linear_projection=True)
     with pytest.raises(RuntimeError):
         M.UNet3DConditionModel.from_pretrained_2d("/nonexistent", "/nonexistent.pth")
+
+
+def test_scene_motion_matches_reference(golden_dir):
+    import numpy as np
+    from mikudance_amd.scene_motion import camera_to_scene_motion
+    z = np.load(os.path.join(golden_dir, "g2_scene_motion.npz"))
+    flow = camera_to_scene_motion(list(z["w2c"]), list(z["c2w"]), list(z["K"]), z["depth"], 24, 24, False)
+    assert flow.shape == (16, 2, 24, 24) and np.abs(flow - z["flow"]).max() <= 1e-12
+    eye = [np.eye(4)] * 5
+    assert np.abs(camera_to_scene_motion(eye, eye, list(z["K"]), np.zeros((1, 24, 24)), 24, 24, False)).max() == 0
