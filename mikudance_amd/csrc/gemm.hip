@@ -6,22 +6,25 @@
 //   PLAIN : A is a row-major [M][lda] fp16 matrix (Linear / 1x1 conv on NHWC tokens).
 //   CONV3 : A is an NHWC fp16 image batch; row m = (b, oy, ox), column k = (ky*3+kx)*Cin + c; zero padding 1,
 //           stride 1 or 2, optional nearest-2x upsample folded into the input addressing.  Cin % 64 == 0 so every
-//           64-wide K chunk lies inside a single filter tap.
+//           K chunk lies inside a single filter tap; out-of-image taps read a 64-byte zero page.
 // Replaces the ATen conv2d / linear calls behind InflatedConv3d (reference src/models/resnet.py:9-17), diffusers
 // ResnetBlock2D/Downsample2D/Upsample2D convs, Attention.to_q/k/v/to_out, FeedForward and the 1x1 proj_in/proj_out
 // of Transformer2D/3DModel.
 //
-// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles).
-// A and W tiles are register-staged (global -> VGPR -> LDS, 16 B per lane, next tile's loads issued before the
-// current tile's MFMAs) into a 2-deep LDS ring with one barrier per K step.  LDS rows are 128 B with the 16-B slot
-// index XOR-swizzled by (row>>1)&7 so that ds_read_b128 fragment reads are bank-conflict free.
-// The fp32 accumulators are staged through LDS in the epilogue so that bias / SiLU / ReLU / GEGLU / row-broadcast
-// (time embedding) / residual are applied on full 16-byte coalesced rows, or stored transposed (V^T for attention).
+// Tile 128x128xBK per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles).
+// Operand tiles go HBM/L2 -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip)
+// into an NSTAGE-deep ring: NSTAGE-1 tiles are in flight while one is being multiplied, waits are COUNTED
+// (s_waitcnt vmcnt(N), never 0 inside the loop) and there is one raw s_barrier per K step.
+// The DMA writes LDS lane-linearly, so the bank-conflict swizzle is applied to the per-lane SOURCE address and to the
+// fragment read address (same involution): the 16-B slot of row r is XORed with (r>>2)&3 (BK=32) / (r>>1)&7 (BK=64),
+// which makes every ds_read_b128 fragment read conflict free.
+// The fp32 accumulators are staged through LDS (two 64-row passes) in the epilogue so that bias / SiLU / ReLU / GEGLU /
+// row-broadcast (time embedding) / residual are applied on full 16-byte coalesced rows, or stored transposed (V^T).
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
-#define BK 64
 #define CS_LD 132  // fp32 staging row pitch
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3 };
@@ -43,18 +46,33 @@ struct GemmParams {
   int tiles_n, tiles_total;
 };
 
-__device__ __forceinline__ int swz_off(int row, int slot) { return row * (BK * 2) + ((slot ^ ((row >> 1) & 7)) << 4); }
+__device__ __attribute__((aligned(64))) half_t g_zero_page[32] = {};
 
-template <bool CONV>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool CONV, int BK, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int ROWB = BK * 2;             // bytes per tile row
+  constexpr int SLOTS = BK / 8;            // 16-B slots per row
+  constexpr int RPI = 1024 / ROWB;         // rows covered by one wave-wide DMA instruction
+  constexpr int IPW = (BM / RPI) / 4;      // DMA instructions per wave per operand per tile
+  constexpr int OPB = BM * ROWB;           // bytes of one operand tile
+  constexpr int STAGE = 2 * OPB;
+  constexpr int G = 2 * IPW;               // DMA instructions per thread per tile
+  constexpr int SW_SHIFT = BK == 32 ? 2 : 1;
+  constexpr int SW_MASK = SLOTS - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                       // 2 stages x 128 rows x 128 B
-  char* Bs = smem + 2 * BM * BK * 2;     // 2 stages x 128 rows x 128 B
   float* Cs = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles (n fastest) so that
@@ -68,74 +86,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- per-thread load coordinates: 4 A chunks + 4 W chunks of 16 B
-  const int slot = tid & 7;
-  const int lrow = tid >> 3;  // 0..31
-  const half_t* a_ptr[4];
-  bool a_ok[4];
-  int a_oy[4], a_ox[4];
-  const half_t* w_ptr[4];
-  bool w_ok[4];
+  // ---- per-lane DMA source coordinates
+  const int lrow = lane / SLOTS, pslot = lane % SLOTS;
+  const half_t* a_src[IPW];
+  const half_t* w_src[IPW];
+  int a_oy[IPW], a_ox[IPW];
+  bool a_ok[IPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = lrow + 32 * i;
+  for (int j = 0; j < IPW; ++j) {
+    const int row = (wave * IPW + j) * RPI + lrow;
+    const int lslot = pslot ^ ((row >> SW_SHIFT) & SW_MASK);
     const int m = m0 + row;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    a_ok[j] = m < p.M;
+    const int mm = a_ok[j] ? m : p.M - 1;
     if (CONV) {
       const int hw = p.Hout * p.Wout;
       const int b = mm / hw, rem = mm - b * hw;
-      a_oy[i] = rem / p.Wout;
-      a_ox[i] = rem - a_oy[i] * p.Wout;
-      a_ptr[i] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + slot * 8;
+      a_oy[j] = rem / p.Wout;
+      a_ox[j] = rem - a_oy[j] * p.Wout;
+      a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
     } else {
-      a_oy[i] = a_ox[i] = 0;
-      a_ptr[i] = p.A + (size_t)mm * p.lda + slot * 8;
+      a_oy[j] = a_ox[j] = 0;
+      a_src[j] = p.A + (size_t)mm * p.lda + lslot * 8;
     }
     const int n = n0 + row;
-    w_ok[i] = n < p.N;
-    w_ptr[i] = p.W + (size_t)(w_ok[i] ? n : 0) * p.K + slot * 8;
+    w_src[j] = p.W + (size_t)(n < p.N ? n : p.N - 1) * p.K + lslot * 8;
   }
+  const half_t* zero_src = g_zero_page + 0;
 
-  half8_t ra[4], rb[4];
-  auto load_tile = [&](int kt) {
+  auto issue_tile = [&](int kt, int stage) {
     const int k0 = kt * BK;
+    char* base = smem + stage * STAGE + (wave * IPW) * 1024;
     if (CONV) {
       const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
       const int hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int iy = a_oy[i] * p.stride + ky - 1, ix = a_ox[i] * p.stride + kx - 1;
-        const bool ok = a_ok[i] && iy >= 0 && iy < hup && ix >= 0 && ix < wup;
-        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) v = *reinterpret_cast<const half8_t*>(a_ptr[i] + ((size_t)(iy >> p.upsample) * p.Win + (ix >> p.upsample)) * p.Cin + c0);
-        ra[i] = v;
+      for (int j = 0; j < IPW; ++j) {
+        const int iy = a_oy[j] * p.stride + ky - 1, ix = a_ox[j] * p.stride + kx - 1;
+        const bool ok = iy >= 0 && iy < hup && ix >= 0 && ix < wup;
+        const half_t* src = ok ? a_src[j] + ((size_t)(iy >> p.upsample) * p.Win + (ix >> p.upsample)) * p.Cin + c0 : zero_src;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + j * 1024), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (a_ok[i]) v = *reinterpret_cast<const half8_t*>(a_ptr[i] + k0);
-        ra[i] = v;
-      }
+      for (int j = 0; j < IPW; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + k0), (lptr_t)(base + j * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (w_ok[i]) v = *reinterpret_cast<const half8_t*>(w_ptr[i] + k0);
-      rb[i] = v;
-    }
-  };
-  auto store_tile = [&](int stage) {
-    char* as = As + stage * (BM * BK * 2);
-    char* bs = Bs + stage * (BN * BK * 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = lrow + 32 * i;
-      *reinterpret_cast<half8_t*>(as + swz_off(row, slot)) = ra[i];
-      *reinterpret_cast<half8_t*>(bs + swz_off(row, slot)) = rb[i];
-    }
+    for (int j = 0; j < IPW; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + k0), (lptr_t)(base + OPB + j * 1024), 16, 0, 0);
   };
 
   floatx16 acc[2][2];
@@ -147,157 +145,264 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue_tile(s, s);
 
   const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+    a_off[i] = ra * ROWB;
+    b_off[i] = OPB + rb * ROWB;
+    a_sw[i] = (ra >> SW_SHIFT) & SW_MASK;
+    b_sw[i] = (rb >> SW_SHIFT) & SW_MASK;
+  }
+
+  int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const char* as = As + stage * (BM * BK * 2);
-    const char* bs = Bs + stage * (BN * BK * 2);
+    // tile kt has landed once at most (tiles still allowed in flight) x G of this wave's DMAs are outstanding
+    const int ahead = nk - 1 - kt;  // tiles issued after kt
+    if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * G>();
+    else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // every wave has finished tile kt-1 -> its ring slot can be refilled with tile kt+NSTAGE-1
+    if (kt + NSTAGE - 1 < nk) {
+      int st = stage + NSTAGE - 1;
+      if (st >= NSTAGE) st -= NSTAGE;
+      issue_tile(kt + NSTAGE - 1, st);
+    }
+    const char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       half8_t af[2], bf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const half8_t*>(as + swz_off(wm * 64 + i * 32 + frow, s * 2 + fhi));
-        bf[i] = *reinterpret_cast<const half8_t*>(bs + swz_off(wn * 64 + i * 32 + frow, s * 2 + fhi));
+        af[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
+        bf[i] = *reinterpret_cast<const half8_t*>(sb + b_off[i] + (((s * 2 + fhi) ^ b_sw[i]) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(stage ^ 1);
-    __syncthreads();
+    if (++stage == NSTAGE) stage = 0;
   }
 
-  // ---- epilogue: accumulators -> LDS (fp32) -> coalesced rows
+  // ---- epilogue: accumulators -> LDS (fp32, 64 rows per pass) -> coalesced rows
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int Nout = p.act == ACT_GEGLU ? p.N >> 1 : p.N;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    // residual rows of this pass (plain epilogue): issue the loads BEFORE the staging barriers so that their HBM
+    // latency overlaps the accumulator -> LDS traffic
+    half8_t rv[4];
+    bool rvec[4];
+    {
+      const int n = n0 + (tid & 15) * 8;
+      const bool nvec = (p.N - n) >= 8;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-        const int col = wn * 64 + j * 32 + frow;
-        Cs[row * CS_LD + col] = acc[i][j][r];
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + pass * 64 + (tid >> 4) + 16 * i;
+        rvec[i] = false;
+        if (p.residual && m < p.M && nvec) {
+          const half_t* rs = p.residual + (size_t)m * p.ldr + n;
+          if ((reinterpret_cast<uintptr_t>(rs) & 15) == 0) {
+            rv[i] = *reinterpret_cast<const half8_t*>(rs);
+            rvec[i] = true;
+          }
+        }
       }
-  __syncthreads();
-
-  if (p.transpose_out) {
-    // out[n][m]: thread owns one column n and 8 consecutive rows -> one 16-B store along m
-    const int col = tid & 127;
-    const int n = n0 + col;
-    if (n < p.N) {
-      const float bv = p.bias ? (float)p.bias[n] : 0.f;
+    }
+    __syncthreads();
+    if (wm == pass) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rc = (tid >> 7) + 2 * i;
-        const int m = m0 + rc * 8;
-        if (m >= p.M) continue;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            const int col = wn * 64 + j * 32 + frow;
+            Cs[row * CS_LD + col] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const int mp = m0 + pass * 64;
+
+    if (p.transpose_out) {
+      // out[n][m]: thread owns one column n and 8 consecutive rows -> one 16-B store along m
+      const int col = tid & 127;
+      const int n = n0 + col;
+      if (n < p.N) {
+        const float bv = p.bias ? (float)p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rc = (tid >> 7) + 2 * i;
+          const int m = mp + rc * 8;
+          if (m >= p.M) continue;
+          half8_t o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (half_t)(Cs[(rc * 8 + j) * CS_LD + col] + bv);
+          half_t* dst = p.C + (size_t)n * p.ldc + m;
+          if (m + 8 <= p.M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            *reinterpret_cast<half8_t*>(dst) = o;
+          } else {
+            for (int j = 0; j < 8 && m + j < p.M; ++j) dst[j] = o[j];
+          }
+        }
+      }
+    } else if (p.act == ACT_GEGLU) {
+      // weight rows were packed as [32 h | 32 g] blocks; the tile holds 64 output columns
+      const int oc8 = (tid & 7) * 8;
+      const int hcol = (oc8 >> 5) * 64 + (oc8 & 31), gcol = hcol + 32;
+      const int nout0 = (n0 >> 1) + oc8;
+      float bh[8], bg[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bh[j] = bg[j] = 0.f;
+      if (p.bias && nout0 < Nout) {
+        const half8_t b1 = *reinterpret_cast<const half8_t*>(p.bias + n0 + hcol);
+        const half8_t b2 = *reinterpret_cast<const half8_t*>(p.bias + n0 + gcol);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bh[j] = (float)b1[j];
+          bg[j] = (float)b2[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = mp + row;
+        if (m >= p.M || nout0 >= Nout) continue;
         half8_t o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(Cs[(rc * 8 + j) * CS_LD + col] + bv);
-        half_t* dst = p.C + (size_t)n * p.ldc + m;
-        if (m + 8 <= p.M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        for (int j = 0; j < 8; ++j) {
+          const float h = Cs[row * CS_LD + hcol + j] + bh[j], g = Cs[row * CS_LD + gcol + j] + bg[j];
+          o[j] = (half_t)(h * gelu_erf_f(g));
+        }
+        *reinterpret_cast<half8_t*>(p.C + (size_t)m * p.ldc + nout0) = o;
+      }
+    } else {
+      const int col8 = (tid & 15) * 8;
+      const int n = n0 + col8;
+      const int nv = (p.N - n) < 8 ? (p.N - n) : 8;   // <= 0: this thread's columns are outside the matrix
+      const bool nvec = nv == 8;
+      float bsum[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+      if (p.bias && nv > 0) {
+        if (nvec && ((reinterpret_cast<uintptr_t>(p.bias + n) & 15) == 0)) {
+          const half8_t bv = *reinterpret_cast<const half8_t*>(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] = (float)bv[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < nv) bsum[j] = (float)p.bias[n + j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i;
+        const int m = mp + row;
+        if (m >= p.M || nv <= 0) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Cs[row * CS_LD + col8 + j] + bsum[j];
+        if (p.rowadd) {
+          const half_t* ra_ = p.rowadd + (size_t)(m / p.rows_per_group) * p.ldra + n;
+          if (nvec && ((reinterpret_cast<uintptr_t>(ra_) & 15) == 0)) {
+            const half8_t av = *reinterpret_cast<const half8_t*>(ra_);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)av[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < nv) v[j] += (float)ra_[j];
+          }
+        }
+        if (p.act == ACT_SILU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+        } else if (p.act == ACT_RELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        half_t* dst = p.C + (size_t)m * p.ldc + n;
+        const bool vec = nvec && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+        if (p.residual) {
+          if (rvec[i]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)rv[i][j];
+          } else {
+            const half_t* rs = p.residual + (size_t)m * p.ldr + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < nv) v[j] += (float)rs[j];
+          }
+        }
+        if (vec) {
+          half8_t o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
           *reinterpret_cast<half8_t*>(dst) = o;
         } else {
-          for (int j = 0; j < 8 && m + j < p.M; ++j) dst[j] = o[j];
+          for (int j = 0; j < nv; ++j) dst[j] = (half_t)v[j];
         }
       }
-    }
-    return;
-  }
-
-  if (p.act == ACT_GEGLU) {
-    // weight rows were packed as [32 h | 32 g] blocks; the tile holds 64 output columns
-    const int oc8 = (tid & 7) * 8;
-    const int hcol = (oc8 >> 5) * 64 + (oc8 & 31), gcol = hcol + 32;
-    const int nout0 = (n0 >> 1) + oc8;
-    const int Nout = p.N >> 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      const int m = m0 + row;
-      if (m >= p.M || nout0 >= Nout) continue;
-      half8_t o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float h = Cs[row * CS_LD + hcol + j], g = Cs[row * CS_LD + gcol + j];
-        if (p.bias) {
-          h += (float)p.bias[n0 + hcol + j];
-          g += (float)p.bias[n0 + gcol + j];
-        }
-        o[j] = (half_t)(h * gelu_erf_f(g));
-      }
-      *reinterpret_cast<half8_t*>(p.C + (size_t)m * p.ldc + nout0) = o;
-    }
-    return;
-  }
-
-  const int col8 = (tid & 15) * 8;
-  const int n = n0 + col8;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (tid >> 4) + 16 * i;
-    const int m = m0 + row;
-    if (m >= p.M || n >= p.N) continue;
-    const int nv = (p.N - n) < 8 ? (p.N - n) : 8;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = Cs[row * CS_LD + col8 + j];
-    if (p.bias) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < nv) v[j] += (float)p.bias[n + j];
-    }
-    if (p.rowadd) {
-      const half_t* ra_ = p.rowadd + (size_t)(m / p.rows_per_group) * p.ldra + n;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < nv) v[j] += (float)ra_[j];
-    }
-    if (p.act == ACT_SILU) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
-    } else if (p.act == ACT_RELU) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
-    half_t* dst = p.C + (size_t)m * p.ldc + n;
-    const bool vec = nv == 8 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-    if (p.residual) {
-      const half_t* rs = p.residual + (size_t)m * p.ldr + n;
-      if (vec && ((reinterpret_cast<uintptr_t>(rs) & 15) == 0)) {
-        const half8_t rv = *reinterpret_cast<const half8_t*>(rs);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < nv) v[j] += (float)rs[j];
-      }
-    }
-    if (vec) {
-      half8_t o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-      *reinterpret_cast<half8_t*>(dst) = o;
-    } else {
-      for (int j = 0; j < nv; ++j) dst[j] = (half_t)v[j];
     }
   }
 }
 
-static const size_t kGemmSmem = (size_t)BM * CS_LD * 4 > (size_t)2 * (BM + BN) * BK * 2 ? (size_t)BM * CS_LD * 4 : (size_t)2 * (BM + BN) * BK * 2;
+// ring geometry variants (MD_GEMM_VARIANT env var, read once; default 0):
+//   0: BK=32 x 4 stages = 64 KiB  -> 2 workgroups/CU, three 16-KiB tiles in flight each
+//   1: BK=32 x 3 stages = 48 KiB  -> 3 workgroups/CU, two tiles in flight each
+//   2: BK=64 x 2 stages = 64 KiB  -> 2 workgroups/CU, one 32-KiB tile in flight each
+//   3: BK=64 x 3 stages = 96 KiB  -> 1 workgroup/CU, two 32-KiB tiles in flight
+static constexpr size_t kCsBytes = (size_t)64 * CS_LD * 4;
+template <int BK, int NSTAGE>
+static constexpr size_t gemm_smem() {
+  return ((size_t)NSTAGE * 2 * BM * BK * 2 > kCsBytes) ? (size_t)NSTAGE * 2 * BM * BK * 2 : kCsBytes;
+}
+
+template <bool CONV, int BK, int NSTAGE>
+static void launch_variant(const GemmParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  constexpr size_t smem = gemm_smem<BK, NSTAGE>();
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE>), dim3(p.tiles_total), dim3(256), smem, stream, p);
+}
+
+static int gemm_variant(bool conv) {
+  // measured on MI355X at the config-2 shapes (tools/bench_kernels.py): the skinny-K Linear GEMMs like 3 workgroups
+  // per CU (variant 1); the 3x3 convs (K = 2880..23040) like the 64-wide K step (variant 2)
+  static int v[2] = {-1, -1};
+  if (v[conv] < 0) {
+    const char* e = getenv(conv ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT");
+    v[conv] = e ? atoi(e) : (conv ? 2 : 1);
+    if (v[conv] < 0 || v[conv] > 3) v[conv] = conv ? 2 : 1;
+  }
+  return v[conv];
+}
+
+template <bool CONV>
+static void launch_any(const GemmParams& p, hipStream_t stream) {
+  switch (gemm_variant(CONV)) {
+    case 0: launch_variant<CONV, 32, 4>(p, stream); break;
+    case 1: launch_variant<CONV, 32, 3>(p, stream); break;
+    case 3: launch_variant<CONV, 64, 3>(p, stream); break;
+    default: launch_variant<CONV, 64, 2>(p, stream); break;
+  }
+}
 
 static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
   MD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "md_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
-  MD_CHECK_ARG(p.K % BK == 0, "md_gemm: K=%d must be a multiple of %d (pad channels when packing)", p.K, BK);
+  MD_CHECK_ARG(p.K % 64 == 0, "md_gemm: K=%d must be a multiple of 64 (pad channels when packing)", p.K);
   MD_CHECK_ARG((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0, "md_gemm: A/W must be 16-byte aligned");
   MD_CHECK_ARG(conv || p.lda % 8 == 0, "md_gemm: lda=%d must be a multiple of 8", p.lda);
   if (p.act == ACT_GEGLU) {
@@ -307,16 +412,10 @@ static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
   if (p.rowadd) MD_CHECK_ARG(p.rows_per_group > 0, "md_gemm: rows_per_group must be > 0 with rowadd");
   p.tiles_n = cdiv(p.N, BN);
   p.tiles_total = cdiv(p.M, BM) * p.tiles_n;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmSmem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmSmem);
-    attr_set = true;
-  }
   if (conv)
-    hipLaunchKernelGGL(gemm_kernel<true>, dim3(p.tiles_total), dim3(256), kGemmSmem, stream, p);
+    launch_any<true>(p, stream);
   else
-    hipLaunchKernelGGL(gemm_kernel<false>, dim3(p.tiles_total), dim3(256), kGemmSmem, stream, p);
+    launch_any<false>(p, stream);
   MD_CHECK_LAUNCH("md_gemm");
   return MD_OK;
 }
@@ -334,7 +433,7 @@ extern "C" int md_gemm_f16(const void* A, int lda, const void* W, void* C, int l
 extern "C" int md_conv3x3_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int stride,
                                    int upsample, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
                                    int rows_per_group, int act, void* stream) {
-  MD_CHECK_ARG(Cin % BK == 0, "md_conv3x3: Cin=%d must be a multiple of %d (zero-pad channels when packing)", Cin, BK);
+  MD_CHECK_ARG(Cin % 64 == 0, "md_conv3x3: Cin=%d must be a multiple of 64 (zero-pad channels when packing)", Cin);
   MD_CHECK_ARG(stride == 1 || stride == 2, "md_conv3x3: stride must be 1 or 2");
   MD_CHECK_ARG(upsample == 0 || (upsample == 1 && stride == 1), "md_conv3x3: upsample is 0 or 1 (nearest 2x) with stride 1");
   GemmParams p = {};

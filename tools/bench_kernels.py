@@ -1,0 +1,77 @@
+"""Kernel micro-benchmarks at the config-2 shapes (HIP events, 10 iterations after 3 warm-ups).  Debug/tuning tool."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mikudance_amd import ops, packing  # noqa: E402
+
+dev = torch.device("cuda")
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).half()
+
+
+def main(which):
+    out = {}
+    if "gemm" in which:
+        for M, N, K, geglu in [(294912, 320, 320, False), (294912, 2560, 320, True), (73728, 640, 640, False), (73728, 5120, 640, True),
+                               (18432, 1280, 1280, False), (18432, 10240, 1280, True), (294912, 320, 1280, False), (294912, 640, 320, False),
+                               (8192, 8192, 8192, False)]:
+            a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+            res = rnd(M, N) if not geglu else None
+            o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=res, act=ops.ACT_GEGLU if geglu else 0, out=o))
+            out[f"gemm {M}x{N}x{K}{' geglu' if geglu else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9)
+    if "conv" in which:
+        for B, H, Cin, Cout in [(32, 96, 320, 320), (32, 48, 640, 640), (32, 24, 1280, 1280), (32, 24, 2560, 1280), (32, 96, 640, 320),
+                                (32, 48, 1280, 640)]:
+            x, w, b = rnd(B, H, H, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5), rnd(Cout)
+            o = torch.empty((B, H, H, Cout), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.conv3x3(x, w, Cout, bias=b, out=o))
+            out[f"conv {B}x{H}x{H} {Cin}->{Cout}"] = (ms, 2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9)
+    if "attn" in which:
+        for B, L, D in [(8, 9216, 40), (32, 2304, 80), (32, 576, 160)]:
+            C = 8 * D
+            q, k, vt = rnd(B * L, C), rnd(B * L, C), rnd(C, B * L)
+            o = torch.empty((B * L, C), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.attention(q, k, vt, B, 8, D, L, L, out=o))
+            out[f"attn B={B} L={L} D={D}"] = (ms, 4.0 * B * 8 * L * L * D / ms / 1e9)
+    if "temporal" in which:
+        for HW, D in [(9216, 40), (2304, 80), (576, 160)]:
+            C, F_ = 8 * D, 16
+            q, k, v = rnd(2 * F_ * HW, C), rnd(2 * F_ * HW, C), rnd(2 * F_ * HW, C)
+            o = torch.empty_like(q)
+            ms = timeit(lambda: ops.temporal_attention(q, k, v, 2, F_, HW, 8, D, out=o))
+            out[f"temporal HW={HW} D={D}"] = (ms, 8.0 * 2 * F_ * HW * C / ms / 1e6)      # GB/s
+    if "norm" in which:
+        for B, HW, C in [(32, 9216, 320), (32, 9216, 640), (32, 2304, 1280)]:
+            x, g, b = rnd(B, HW, C), rnd(C), rnd(C)
+            o = torch.empty_like(x)
+            ms = timeit(lambda: ops.groupnorm(x, g, b, 32, 1e-5, True, out=o))
+            out[f"groupnorm {B}x{HW}x{C}"] = (ms, 6.0 * B * HW * C / ms / 1e6)
+            x2 = x.view(-1, C)
+            ms = timeit(lambda: ops.layernorm(x2, g, b))
+            out[f"layernorm {B * HW}x{C}"] = (ms, 4.0 * B * HW * C / ms / 1e6)
+    for k, (ms, rate) in out.items():
+        print(f"{k:44s} {ms:9.3f} ms  {rate:10.1f} {'GB/s' if k.startswith(('temporal', 'groupnorm', 'layernorm')) else 'TFLOP/s'}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or ["gemm", "conv", "attn", "temporal", "norm"])
