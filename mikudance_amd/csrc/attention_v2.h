@@ -1,0 +1,244 @@
+// attn2_kernel<D>: the fast path of md_attention_fwd_f16 (aligned K / V^T: every shape of the UNets at latent sizes that
+// are multiples of 8; the cross-attention context is padded to a multiple of 8 tokens).  Same math and layouts as
+// attn_kernel<D> (attention.hip), restructured around what limited that kernel on MI355X (VALU work and stalls, not MFMA):
+//
+//  * K and V^T tiles (64 keys) go HBM/L2 -> LDS by direct-to-LDS DMA into a 3-deep ring with counted vmcnt waits and one
+//    raw s_barrier per tile (no VGPR staging, two tiles in flight).
+//  * The K rows fed to MFMA row index i are the keys kappa(i) = i with bits 2 and 3 swapped.  With that choice the
+//    32x32 C layout of S^T leaves every lane holding, per 16-key step, EIGHT CONSECUTIVE keys, so the P fragment pairs
+//    with ONE ds_read_b128 of a plain row-major V^T tile (16-B slots XOR-swizzled on the DMA source side).
+//  * The softmax denominator is produced by the matrix core: a constant row of ones appended to V^T (free whenever
+//    D % 32 != 0: head dims 40 and 80 pad to 64 / 96 rows anyway) makes row D of O^T accumulate sum_k P[k] in fp32 from
+//    the same fp16-rounded P as the numerator.
+//  * The O^T rescale is skipped unless some row's running maximum grows by more than 2^5 (wave-uniform test, exact
+//    arithmetic otherwise: P <= 32 in fp16 keeps its relative precision).
+//  * P is packed with v_cvt_pk_f16_f32 (round to nearest).
+#pragma once
+#include "common.h"
+
+#define A2_KT 64
+#define A2_THR 5.0f
+
+template <int N>
+__device__ __forceinline__ void a2_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void a2_wait_dyn(int n) {
+  switch (n) {
+    case 0: a2_wait<0>(); break;
+    case 1: a2_wait<1>(); break;
+    case 2: a2_wait<2>(); break;
+    case 3: a2_wait<3>(); break;
+    case 4: a2_wait<4>(); break;
+    case 5: a2_wait<5>(); break;
+    case 6: a2_wait<6>(); break;
+    case 8: a2_wait<8>(); break;
+    case 10: a2_wait<10>(); break;
+    case 12: a2_wait<12>(); break;
+    case 16: a2_wait<16>(); break;
+    case 20: a2_wait<20>(); break;
+    default: a2_wait<0>(); break;
+  }
+}
+
+template <int D, int NST>
+__global__ __launch_bounds__(256) void attn2_kernel(AttnParams p) {
+  constexpr int KS = (D + 15) / 16;            // k-steps of Q K^T
+  constexpr bool ONES = (D % 32) != 0;         // room for the ones row in the last O^T tile
+  constexpr int DVT = (D + 31) / 32;           // 32-row tiles of O^T
+  constexpr int KROWB = D * 2;                 // bytes per K row in LDS (unpadded: DMA image is lane linear)
+  constexpr int KBYTES = A2_KT * KROWB;
+  constexpr int VBYTES = DVT * 32 * 128;       // V^T rows of 64 keys = 128 B
+  constexpr int STAGE = KBYTES + VBYTES;
+  constexpr int NKI = KBYTES / 1024, NVI = (D * 128) / 1024;  // DMA instructions per tile (K, V^T)
+  constexpr int NI = NKI + NVI;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kb = p.kv_index ? p.kv_index[b] : b;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = min(q0 + ql, p.Lq - 1);
+  const int lk8 = (p.Lk + 7) & ~7;
+
+  const half_t* Qp = p.Q + ((size_t)b * p.Lq + qrow) * p.ldq + h * D;
+  const half_t* Kb = p.K + (size_t)kb * p.kv_stride * p.ldk + h * D;
+  const half_t* Vb = p.Vt + (size_t)h * D * p.ldvt + (size_t)kb * p.kv_stride;
+
+  // constant rows of every V^T stage: ones in row D (softmax denominator), zeros in the rest of the padding
+  if (D % 32 != 0) {
+    for (int i = tid; i < NST * (DVT * 32 - D) * 8; i += 256) {
+      const int st = i / ((DVT * 32 - D) * 8), rem = i % ((DVT * 32 - D) * 8);
+      const int row = D + rem / 8, slot = rem % 8;
+      const half_t v = row == D ? (half_t)1.0f : (half_t)0.0f;
+      half8_t w = {v, v, v, v, v, v, v, v};
+      *reinterpret_cast<half8_t*>(smem + st * STAGE + KBYTES + row * 128 + slot * 16) = w;
+    }
+  }
+
+  half8_t qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int c = s * 16 + hi * 8;
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < D) v = *reinterpret_cast<const half8_t*>(Qp + c);
+    qf[s] = v;
+  }
+
+  // ---- DMA: instruction q of a tile (q < NKI: K image, else V^T image) is issued by wave q % 4
+  const int n_mine = (NI - wave + 3) / 4;
+  auto issue_tile = [&](int j0, int stage) {
+    char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int qi = 0; qi < (NI + 3) / 4; ++qi) {
+      const int q = qi * 4 + wave;
+      if (q < NKI) {
+        const int o = q * 1024 + lane * 16;
+        const int row = o / KROWB, cb = o - row * KROWB;
+        const int key = min(j0 + row, p.Lk - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(Kb + (size_t)key * p.ldk) + cb), (lptr_t)(sb + q * 1024), 16, 0, 0);
+      } else if (q < NI) {
+        const int qv = q - NKI;
+        const int o = qv * 1024 + lane * 16;
+        const int dv = o >> 7, ps = (o & 127) >> 4;
+        const int ls = ps ^ ((dv >> 1) & 7);
+        const int j = min(j0 + ls * 8, lk8 - 8);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Vb + (size_t)dv * p.ldvt + j), (lptr_t)(sb + KBYTES + qv * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  floatx16 o[DVT];
+#pragma unroll
+  for (int t = 0; t < DVT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = p.scale_log2;
+  const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < ntiles) issue_tile(s * A2_KT, s);
+
+  // K row read by MFMA row index ql: key kappa(ql) = ql with bits 2 and 3 swapped
+  const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+  const int vsw = (ql >> 1) & 7;  // V^T slot swizzle of row t*32 + ql: ((row >> 1) & 7), 32 | row offset keeps it
+  int stage = 0;
+  for (int it = 0; it < ntiles; ++it) {
+    const int j0 = it * A2_KT;
+    const int ahead = min(NST - 2, ntiles - 1 - it);
+    a2_wait_dyn(ahead * n_mine);
+    __builtin_amdgcn_s_barrier();
+    if (it + NST - 1 < ntiles) {
+      int st = stage + NST - 1;
+      if (st >= NST) st -= NST;
+      issue_tile((it + NST - 1) * A2_KT, st);
+    }
+    const char* ks = smem + stage * STAGE;
+    const char* vs = ks + KBYTES;
+
+    // ---- S^T = K Q^T  (2 sub-tiles of 32 keys, MFMA row i <-> key kappa(i))
+    floatx16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[k], s[sub], 0, 0, 0);
+      }
+    }
+    // register r of sub-tile `sub` in lane half `hi` holds key j0 + sub*32 + 16*(r>>3) + 8*hi + (r&7)
+    if (j0 + A2_KT > p.Lk) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= p.Lk) s[sub][r] = NEG_BIG;
+        }
+    }
+    float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[0][r]), s[1][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mt = mloc * sc;
+    float lsum = 0.f;
+    if (!__all(mt <= m_run + A2_THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
+    half8_t pf[4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s[sub][r] * sc - m_run);
+        const float p1 = __builtin_amdgcn_exp2f(s[sub][r + 1] * sc - m_run);
+        if (!ONES) lsum += p0 + p1;
+        pf[sub * 2 + (r >> 3)][r & 7] = (half_t)p0;
+        pf[sub * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
+      }
+    if (!ONES) l_run += lsum;
+    // ---- O^T += V^T P^T : one ds_read_b128 per MFMA
+#pragma unroll
+    for (int t = 0; t < DVT; ++t) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const half8_t vf = *reinterpret_cast<const half8_t*>(vs + (t * 32 + ql) * 128 + (((k * 2 + hi) ^ vsw) << 4));
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k], o[t], 0, 0, 0);
+      }
+    }
+    if (++stage == NST) stage = 0;
+  }
+
+  float l_tot;
+  if (ONES) {
+    constexpr int rt = D % 32;                       // row of the ones inside the last tile; rt % 8 == 0 -> lane half 0
+    constexpr int reg = (rt & 3) + 4 * (rt >> 3);
+    l_tot = __shfl(o[DVT - 1][reg], ql, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
+  const float inv = 1.0f / l_tot;
+  if (q0 + ql < p.Lq) {
+    half_t* Op = p.O + ((size_t)b * p.Lq + q0 + ql) * p.ldo + h * D;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = t * 32 + 8 * g + 4 * hi;
+        if (dv < D) {
+          half4_t ov = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv), (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+          *reinterpret_cast<half4_t*>(Op + dv) = ov;
+        }
+      }
+  }
+}
+
+template <int D>
+static int launch_attn2(const AttnParams& p, hipStream_t stream) {
+  constexpr int NST = D > 80 ? 2 : 3;
+  constexpr int DVT = (D + 31) / 32;
+  constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<D, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.Lq, 128), p.H, p.B);
+  hipLaunchKernelGGL((attn2_kernel<D, NST>), grid, dim3(256), smem, stream, p);
+  MD_CHECK_LAUNCH("md_attention_fwd");
+  return MD_OK;
+}

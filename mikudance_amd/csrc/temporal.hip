@@ -14,26 +14,59 @@ struct TemporalParams {
   half_t* O;
   int ldq, ldk, ldv, ldo;
   int NB, F, HW, H, D;  // NB clip-halves, F frames, D head dim
-  int pix_per_block;
+  int PB, HG;           // pixels and heads per workgroup
   float scale_log2;
 };
 
+// Workgroup = PB pixels x HG heads x F query frames (one lane each).  The K and V rows of those pixels/heads for ALL F
+// frames are first staged in LDS with fully coalesced 16-byte loads (every K/V byte is read from HBM exactly once and
+// then re-used by the F query lanes from LDS: ds_read_b128, conflict free because the HG head-lanes sit D*2 bytes
+// apart and the F frame-lanes broadcast).
 template <int FMAX>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
-  const int h = t % p.H;
-  const int i = (t / p.H) % p.F;
-  const int pl = t / (p.H * p.F);
-  if (pl >= p.pix_per_block) return;
-  const long gp = (long)blockIdx.x * p.pix_per_block + pl;  // global (b, pixel)
-  if (gp >= (long)p.NB * p.HW) return;
+  const int CW = p.HG * p.D;                       // staged columns per row
+  const int cw8 = CW >> 3;
+  const int ngrp = p.H / p.HG;
+  const int grp = blockIdx.x % ngrp;
+  const long pg = (long)(blockIdx.x / ngrp) * p.PB;  // first global (b, pixel) of this workgroup
+  const long npix = (long)p.NB * p.HW;
+  const int col0 = grp * CW;
+  half_t* Ks = reinterpret_cast<half_t*>(smem);
+  half_t* Vs = Ks + (size_t)p.F * p.PB * CW;
+
+  // ---- stage K and V: chunk id -> (frame j, pixel pl, 16-B column chunk)
+  const int nchunk = p.F * p.PB * cw8;
+  for (int c = t; c < nchunk; c += blockDim.x) {
+    const int cc = c % cw8;
+    const int pl = (c / cw8) % p.PB;
+    const int j = c / (cw8 * p.PB);
+    const long gp = pg + pl;
+    half8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (gp < npix) {
+      const int b = (int)(gp / p.HW), pix = (int)(gp % p.HW);
+      const size_t row = ((size_t)b * p.F + j) * p.HW + pix;
+      kv = *reinterpret_cast<const half8_t*>(p.K + row * p.ldk + col0 + cc * 8);
+      vv = *reinterpret_cast<const half8_t*>(p.V + row * p.ldv + col0 + cc * 8);
+    }
+    *reinterpret_cast<half8_t*>(Ks + (size_t)c * 8) = kv;
+    *reinterpret_cast<half8_t*>(Vs + (size_t)c * 8) = vv;
+  }
+  __syncthreads();
+
+  const int hl = t % p.HG;
+  const int i = (t / p.HG) % p.F;
+  const int pl = t / (p.HG * p.F);
+  const long gp = pg + pl;
+  if (pl >= p.PB || gp >= npix) return;
   const int b = (int)(gp / p.HW), pix = (int)(gp % p.HW);
-  const size_t row0 = (size_t)b * p.F * p.HW + pix;  // row of frame 0; frame j is row0 + j*HW
-  const int col = h * p.D;
-  const half_t* qp = p.Q + (row0 + (size_t)i * p.HW) * p.ldq + col;
-  const half_t* kp = p.K + row0 * p.ldk + col;
-  const half_t* vp = p.V + row0 * p.ldv + col;
-  half_t* op = p.O + (row0 + (size_t)i * p.HW) * p.ldo + col;
+  const size_t qrow = ((size_t)b * p.F + i) * p.HW + pix;
+  const half_t* qp = p.Q + qrow * p.ldq + col0 + hl * p.D;
+  half_t* op = p.O + qrow * p.ldo + col0 + hl * p.D;
+  const half_t* kp = Ks + (size_t)pl * CW + hl * p.D;   // frame j at + j * PB * CW
+  const half_t* vp = Vs + (size_t)pl * CW + hl * p.D;
+  const int fstride = p.PB * CW;
   const int nch = p.D >> 3;
 
   float s[FMAX];
@@ -44,7 +77,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 #pragma unroll
     for (int j = 0; j < FMAX; ++j) {
       if (j < p.F) {
-        const half8_t k8 = *reinterpret_cast<const half8_t*>(kp + (size_t)j * p.HW * p.ldk + c * 8);
+        const half8_t k8 = *reinterpret_cast<const half8_t*>(kp + j * fstride + c * 8);
         float a = s[j];
 #pragma unroll
         for (int e = 0; e < 8; e += 2) a = __builtin_amdgcn_fdot2(half2_t{q8[e], q8[e + 1]}, half2_t{k8[e], k8[e + 1]}, a, false);
@@ -74,7 +107,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 #pragma unroll
     for (int j = 0; j < FMAX; ++j) {
       if (j < p.F) {
-        const half8_t v8 = *reinterpret_cast<const half8_t*>(vp + (size_t)j * p.HW * p.ldv + c * 8);
+        const half8_t v8 = *reinterpret_cast<const half8_t*>(vp + j * fstride + c * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += s[j] * (float)v8[e];
       }
@@ -86,23 +119,43 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   }
 }
 
+template <int FMAX>
+static void launch_temporal(const TemporalParams& p, int grid, int threads, size_t smem, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_kernel<FMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(temporal_attn_kernel<FMAX>, dim3(grid), dim3(threads), smem, st, p);
+}
+
 extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int NB, int F, int HW,
                                              int H, int D, float scale, void* stream) {
   MD_CHECK_ARG(F >= 1 && F <= 32, "md_temporal_attention_fwd: F=%d frames, the positional-encoding table holds 32", F);
   MD_CHECK_ARG(D % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "md_temporal_attention_fwd: D and strides must be multiples of 8");
-  MD_CHECK_ARG(H * F <= 256, "md_temporal_attention_fwd: H*F=%d exceeds the 256-thread workgroup", H * F);
+  MD_CHECK_ARG(H >= 1 && H <= 8 && (H & (H - 1)) == 0, "md_temporal_attention_fwd: H=%d heads must be a power of two <= 8", H);
   TemporalParams p;
   p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.NB = NB; p.F = F; p.HW = HW; p.H = H; p.D = D;
-  p.pix_per_block = 256 / (H * F);
+  // heads per workgroup: as many as keep one pixel's K+V (4*F*HG*D bytes) within 48 KiB and HG*F lanes within 256
+  int HG = H;
+  while (HG > 1 && ((size_t)4 * F * HG * D > 48 * 1024 || HG * F > 256)) HG >>= 1;
+  MD_CHECK_ARG((size_t)4 * F * HG * D <= 96 * 1024 && HG * F <= 256, "md_temporal_attention_fwd: F*D too large for LDS");
+  int PB = 256 / (HG * F);
+  const int pb_lds = (int)((48 * 1024) / ((size_t)4 * F * HG * D));
+  if (PB > pb_lds) PB = pb_lds;
+  if (PB < 1) PB = 1;
+  p.PB = PB; p.HG = HG;
   p.scale_log2 = scale * 1.4426950408889634f;
-  const int grid = cdiv((long)NB * HW, p.pix_per_block);
+  const int threads = ((PB * HG * F + 63) / 64) * 64;
+  const size_t smem = (size_t)4 * F * PB * HG * D;
+  const int grid = cdiv((long)NB * HW, PB) * (H / HG);
   hipStream_t st = (hipStream_t)stream;
-  if (F <= 4) hipLaunchKernelGGL(temporal_attn_kernel<4>, dim3(grid), dim3(256), 0, st, p);
-  else if (F <= 8) hipLaunchKernelGGL(temporal_attn_kernel<8>, dim3(grid), dim3(256), 0, st, p);
-  else if (F <= 16) hipLaunchKernelGGL(temporal_attn_kernel<16>, dim3(grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(temporal_attn_kernel<32>, dim3(grid), dim3(256), 0, st, p);
+  if (F <= 4) launch_temporal<4>(p, grid, threads, smem, st);
+  else if (F <= 8) launch_temporal<8>(p, grid, threads, smem, st);
+  else if (F <= 16) launch_temporal<16>(p, grid, threads, smem, st);
+  else launch_temporal<32>(p, grid, threads, smem, st);
   MD_CHECK_LAUNCH("md_temporal_attention_fwd");
   return MD_OK;
 }
