@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (CONV) {
       const int hw = p.Hout * p.Wout;
       const int b = mm / hw, rem = mm - b * hw;
-      a_oy[j] = rem / p.Wout;
-      a_ox[j] = rem - a_oy[j] * p.Wout;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      a_oy[j] = oy * p.stride - 1;          // input row of filter tap ky = 0 (in the possibly upsampled image)
+      a_ox[j] = ox * p.stride - 1;
       a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
     } else {
       a_oy[j] = a_ox[j] = 0;
@@ -120,12 +121,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (CONV) {
       const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
-      const int hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
+      const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
 #pragma unroll
       for (int j = 0; j < IPW; ++j) {
-        const int iy = a_oy[j] * p.stride + ky - 1, ix = a_ox[j] * p.stride + kx - 1;
-        const bool ok = iy >= 0 && iy < hup && ix >= 0 && ix < wup;
-        const half_t* src = ok ? a_src[j] + ((size_t)(iy >> p.upsample) * p.Win + (ix >> p.upsample)) * p.Cin + c0 : zero_src;
+        // branch-free: the element offset is computed for every lane (24-bit multiplies), then the pointer is swapped
+        // for the zero page where the tap falls outside the image
+        const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
+        const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
+        unsigned off = __umul24(__umul24((unsigned)(iy >> p.upsample), (unsigned)p.Win) + (unsigned)(ix >> p.upsample), (unsigned)p.Cin) + c0;
+        asm volatile("" : "+v"(off));
+        const half_t* src = a_src[j] + off;
+        src = ok ? src : zero_src;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + j * 1024), 16, 0, 0);
       }
     } else {

@@ -11,7 +11,7 @@ from mikudance_amd import ops, packing  # noqa: E402
 dev = torch.device("cuda")
 
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=int(os.environ.get("MD_ITERS", "10")), warm=int(os.environ.get("MD_WARM", "3"))):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
