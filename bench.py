@@ -147,6 +147,12 @@ def main():
     top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]
     line["top_launch_shapes"] = [dict(label=k, ms_per_clip=v["ms"] / args.steps, launches=v["count"] // args.steps,
                                       tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None) for k, v in top]
+    if os.environ.get("MD_BENCH_DUMP"):
+        with open(os.environ["MD_BENCH_DUMP"], "w") as fh:
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                fh.write(f"{v['ms'] / args.steps:10.3f} ms/clip  {v['count'] // args.steps:6d} launches  "
+                         f"{(v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else 0:8.1f} TF  "
+                         f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}\n")
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ref_sd, den_sd, args, ctx)
     print(json.dumps(line))

@@ -15,6 +15,7 @@
 //  * P is packed with v_cvt_pk_f16_f32 (round to nearest).
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 #define A2_KT 64
 #define A2_THR 5.0f
@@ -41,8 +42,14 @@ __device__ __forceinline__ void a2_wait_dyn(int n) {
   }
 }
 
-template <int D, int NST>
-__global__ __launch_bounds__(256) void attn2_kernel(AttnParams p) {
+__device__ __forceinline__ float a2_xhalf_max(float x) {
+  // max of the two lane halves (lane l <-> l^32) without going through LDS: v_permlane32_swap
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int D, int NST, int QT, int WPS>
+__global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   constexpr int KS = (D + 15) / 16;            // k-steps of Q K^T
   constexpr bool ONES = (D % 32) != 0;         // room for the ones row in the last O^T tile
   constexpr int DVT = (D + 31) / 32;           // 32-row tiles of O^T
@@ -61,11 +68,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p) {
   const int ql = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int kb = p.kv_index ? p.kv_index[b] : b;
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  const int qrow = min(q0 + ql, p.Lq - 1);
+  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
   const int lk8 = (p.Lk + 7) & ~7;
 
-  const half_t* Qp = p.Q + ((size_t)b * p.Lq + qrow) * p.ldq + h * D;
   const half_t* Kb = p.K + (size_t)kb * p.kv_stride * p.ldk + h * D;
   const half_t* Vb = p.Vt + (size_t)h * D * p.ldvt + (size_t)kb * p.kv_stride;
 
@@ -80,13 +85,18 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p) {
     }
   }
 
-  half8_t qf[KS];
+  half8_t qf[QT][KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int c = s * 16 + hi * 8;
-    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < D) v = *reinterpret_cast<const half8_t*>(Qp + c);
-    qf[s] = v;
+  for (int u = 0; u < QT; ++u) {
+    const int qrow = min(q0 + u * 32 + ql, p.Lq - 1);
+    const half_t* Qp = p.Q + ((size_t)b * p.Lq + qrow) * p.ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = s * 16 + hi * 8;
+      half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < D) v = *reinterpret_cast<const half8_t*>(Qp + c);
+      qf[u][s] = v;
+    }
   }
 
   // ---- DMA: instruction q of a tile (q < NKI: K image, else V^T image) is issued by wave q % 4
@@ -112,12 +122,17 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p) {
     }
   };
 
-  floatx16 o[DVT];
+  floatx16 o[QT][DVT];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int t = 0; t < DVT; ++t)
+  for (int u = 0; u < QT; ++u) {
+    m_run[u] = NEG_BIG;
+    l_run[u] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[u][t][r] = 0.f;
+  }
   const float sc = p.scale_log2;
   const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;
 #pragma unroll
@@ -141,104 +156,135 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p) {
     const char* ks = smem + stage * STAGE;
     const char* vs = ks + KBYTES;
 
-    // ---- S^T = K Q^T  (2 sub-tiles of 32 keys, MFMA row i <-> key kappa(i))
-    floatx16 s[2];
+    // ---- S^T = K Q^T  (2 sub-tiles of 32 keys, MFMA row i <-> key kappa(i)); K fragments shared by the QT q-tiles
+    floatx16 s[QT][2];
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][sub][r] = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-#pragma unroll
       for (int k = 0; k < KS; ++k) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[k], s[sub], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][k], s[u][sub], 0, 0, 0);
       }
     }
     // register r of sub-tile `sub` in lane half `hi` holds key j0 + sub*32 + 16*(r>>3) + 8*hi + (r&7)
     if (j0 + A2_KT > p.Lk) {
 #pragma unroll
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = j0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+            if (key >= p.Lk) s[u][sub][r] = NEG_BIG;
+          }
+    }
+    half8_t pf[QT][4];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      float mloc = fmaxf(s[u][0][0], s[u][1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[u][0][r]), s[u][1][r]);
+      mloc = a2_xhalf_max(mloc);
+      const float mt = mloc * sc;
+      if (!__all(mt <= m_run[u] + A2_THR)) {
+        const float m_new = fmaxf(m_run[u], mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+        m_run[u] = m_new;
+        l_run[u] *= alpha;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[u][t][r] *= alpha;
+      }
+      float lsum = 0.f;
+#pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = j0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-          if (key >= p.Lk) s[sub][r] = NEG_BIG;
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(s[u][sub][r] * sc - m_run[u]);
+          const float p1 = __builtin_amdgcn_exp2f(s[u][sub][r + 1] * sc - m_run[u]);
+          if (!ONES) lsum += p0 + p1;
+          pf[u][sub * 2 + (r >> 3)][r & 7] = (half_t)p0;
+          pf[u][sub * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
         }
+      if (!ONES) l_run[u] += lsum;
     }
-    float mloc = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[0][r]), s[1][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float mt = mloc * sc;
-    float lsum = 0.f;
-    if (!__all(mt <= m_run + A2_THR)) {
-      const float m_new = fmaxf(m_run, mt);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int t = 0; t < DVT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-    }
-    half8_t pf[4];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(s[sub][r] * sc - m_run);
-        const float p1 = __builtin_amdgcn_exp2f(s[sub][r + 1] * sc - m_run);
-        if (!ONES) lsum += p0 + p1;
-        pf[sub * 2 + (r >> 3)][r & 7] = (half_t)p0;
-        pf[sub * 2 + (r >> 3)][(r & 7) + 1] = (half_t)p1;
-      }
-    if (!ONES) l_run += lsum;
-    // ---- O^T += V^T P^T : one ds_read_b128 per MFMA
+    // ---- O^T += V^T P^T : one ds_read_b128 per V^T fragment, shared by the QT q-tiles
 #pragma unroll
     for (int t = 0; t < DVT; ++t) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const half8_t vf = *reinterpret_cast<const half8_t*>(vs + (t * 32 + ql) * 128 + (((k * 2 + hi) ^ vsw) << 4));
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k], o[t], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][k], o[u][t], 0, 0, 0);
       }
     }
     if (++stage == NST) stage = 0;
   }
 
-  float l_tot;
-  if (ONES) {
-    constexpr int rt = D % 32;                       // row of the ones inside the last tile; rt % 8 == 0 -> lane half 0
-    constexpr int reg = (rt & 3) + 4 * (rt >> 3);
-    l_tot = __shfl(o[DVT - 1][reg], ql, 64);
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  }
-  const float inv = 1.0f / l_tot;
-  if (q0 + ql < p.Lq) {
-    half_t* Op = p.O + ((size_t)b * p.Lq + q0 + ql) * p.ldo + h * D;
 #pragma unroll
-    for (int t = 0; t < DVT; ++t)
+  for (int u = 0; u < QT; ++u) {
+    float l_tot;
+    if (ONES) {
+      constexpr int rt = D % 32;                       // row of the ones inside the last tile; rt % 8 == 0 -> lane half 0
+      constexpr int reg = (rt & 3) + 4 * (rt >> 3);
+      l_tot = __shfl(o[u][DVT - 1][reg], ql, 64);
+    } else {
+      l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+    }
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + u * 32 + ql;
+    if (qr < p.Lq) {
+      half_t* Op = p.O + ((size_t)b * p.Lq + qr) * p.ldo + h * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = t * 32 + 8 * g + 4 * hi;
-        if (dv < D) {
-          half4_t ov = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv), (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
-          *reinterpret_cast<half4_t*>(Op + dv) = ov;
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dv = t * 32 + 8 * g + 4 * hi;
+          if (dv < D) {
+            half4_t ov = {(half_t)(o[u][t][4 * g] * inv), (half_t)(o[u][t][4 * g + 1] * inv), (half_t)(o[u][t][4 * g + 2] * inv),
+                          (half_t)(o[u][t][4 * g + 3] * inv)};
+            *reinterpret_cast<half4_t*>(Op + dv) = ov;
+          }
         }
-      }
+    }
   }
 }
 
-template <int D>
-static int launch_attn2(const AttnParams& p, hipStream_t stream) {
-  constexpr int NST = D > 80 ? 2 : 3;
+template <int D, int QT>
+static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
+  constexpr int NST = D > 40 ? 2 : 3;
+  // occupancy targets that fit without spilling: D <= 40 -> 4 waves/SIMD (<= 128 registers), D <= 80 -> 3 (<= 168)
+  constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 4 : (D <= 80 ? 3 : 1));
   constexpr int DVT = (D + 31) / 32;
   constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<D, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<D, NST, QT, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  dim3 grid(cdiv(p.Lq, 128), p.H, p.B);
-  hipLaunchKernelGGL((attn2_kernel<D, NST>), grid, dim3(256), smem, stream, p);
+  dim3 grid(cdiv(p.Lq, 128 * QT), p.H, p.B);
+  hipLaunchKernelGGL((attn2_kernel<D, NST, QT, WPS>), grid, dim3(256), smem, stream, p);
   MD_CHECK_LAUNCH("md_attention_fwd");
   return MD_OK;
+}
+
+template <int D>
+static int launch_attn2(const AttnParams& p, hipStream_t stream) {
+  // two 32-row q-tiles per wave (independent softmax chains interleave with the other tile's MFMAs and every K / V^T
+  // fragment read feeds two MFMAs) when the head dim leaves the registers for it and there are enough query rows
+  static int qt_env = -1;
+  if (qt_env < 0) qt_env = getenv("MD_ATTN_QT") ? atoi(getenv("MD_ATTN_QT")) : 0;
+  if constexpr (D <= 80) {
+    const bool two = qt_env == 2;   // measured slower on MI355X (1 wave/SIMD, the compiler does not interleave the chains)
+    if (two) return launch_attn2_qt<D, 2>(p, stream);
+  }
+  return launch_attn2_qt<D, 1>(p, stream);
 }

@@ -56,8 +56,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool CONV, int BK, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+template <bool CONV, int BK, int NSTAGE, int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
   constexpr int ROWB = BK * 2;             // bytes per tile row
   constexpr int SLOTS = BK / 8;            // 16-B slots per row
   constexpr int RPI = 1024 / ROWB;         // rows covered by one wave-wide DMA instruction
@@ -373,15 +373,15 @@ static constexpr size_t gemm_smem() {
   return ((size_t)NSTAGE * 2 * BM * BK * 2 > kCsBytes) ? (size_t)NSTAGE * 2 * BM * BK * 2 : kCsBytes;
 }
 
-template <bool CONV, int BK, int NSTAGE>
+template <bool CONV, int BK, int NSTAGE, int WPS = 1>
 static void launch_variant(const GemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
   constexpr size_t smem = gemm_smem<BK, NSTAGE>();
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE>), dim3(p.tiles_total), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WPS>), dim3(p.tiles_total), dim3(256), smem, stream, p);
 }
 
 static int gemm_variant(bool conv) {
@@ -391,7 +391,7 @@ static int gemm_variant(bool conv) {
   if (v[conv] < 0) {
     const char* e = getenv(conv ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT");
     v[conv] = e ? atoi(e) : (conv ? 2 : 1);
-    if (v[conv] < 0 || v[conv] > 3) v[conv] = conv ? 2 : 1;
+    if (v[conv] < 0 || v[conv] > 5) v[conv] = conv ? 2 : 1;
   }
   return v[conv];
 }
@@ -402,6 +402,8 @@ static void launch_any(const GemmParams& p, hipStream_t stream) {
     case 0: launch_variant<CONV, 32, 4>(p, stream); break;
     case 1: launch_variant<CONV, 32, 3>(p, stream); break;
     case 3: launch_variant<CONV, 64, 3>(p, stream); break;
+    case 4: launch_variant<CONV, 32, 2, 4>(p, stream); break;
+    case 5: launch_variant<CONV, 32, 3, 3>(p, stream); break;
     default: launch_variant<CONV, 64, 2>(p, stream); break;
   }
 }
