@@ -6,24 +6,26 @@
 //   PLAIN : A is a row-major [M][lda] fp16 matrix (Linear / 1x1 conv on NHWC tokens).
 //   CONV3 : A is an NHWC fp16 image batch; row m = (b, oy, ox), column k = (ky*3+kx)*Cin + c; zero padding 1,
 //           stride 1 or 2, optional nearest-2x upsample folded into the input addressing.  Cin % 64 == 0 so every
-//           K chunk lies inside a single filter tap; out-of-image taps read a 64-byte zero page.
+//           K chunk lies inside a single filter tap; out-of-image taps read a 64-byte zero page (branch-free select).
 // Replaces the ATen conv2d / linear calls behind InflatedConv3d (reference src/models/resnet.py:9-17), diffusers
 // ResnetBlock2D/Downsample2D/Upsample2D convs, Attention.to_q/k/v/to_out, FeedForward and the 1x1 proj_in/proj_out
 // of Transformer2D/3DModel.
 //
-// Tile 128x128xBK per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles).
+// Tile (64*WM) x 128 x BK per workgroup of 2*WM waves (wave grid WM x 2, 64x64 per wave = 2x2 MFMA 32x32 tiles):
+//   WM = 2: 128x128, 256 threads (skinny / small problems, up to 3 workgroups per CU)
+//   WM = 4: 256x128, 512 threads, 3-deep ring of 48-KiB stages (large problems: 25 % fewer operand bytes per MFMA)
 // Operand tiles go HBM/L2 -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip)
 // into an NSTAGE-deep ring: NSTAGE-1 tiles are in flight while one is being multiplied, waits are COUNTED
-// (s_waitcnt vmcnt(N), never 0 inside the loop) and there is one raw s_barrier per K step.
+// (s_waitcnt vmcnt(N), never 0 inside the loop while tiles remain) and there is one raw s_barrier per K step.
 // The DMA writes LDS lane-linearly, so the bank-conflict swizzle is applied to the per-lane SOURCE address and to the
 // fragment read address (same involution): the 16-B slot of row r is XORed with (r>>2)&3 (BK=32) / (r>>1)&7 (BK=64),
 // which makes every ds_read_b128 fragment read conflict free.
-// The fp32 accumulators are staged through LDS (two 64-row passes) in the epilogue so that bias / SiLU / ReLU / GEGLU /
-// row-broadcast (time embedding) / residual are applied on full 16-byte coalesced rows, or stored transposed (V^T).
+// The fp32 accumulators are staged through LDS (64-row passes) in the epilogue so that bias / SiLU / ReLU / GEGLU /
+// row-broadcast (time embedding) / residual are applied on full 16-byte coalesced rows, or stored transposed (V^T);
+// residual rows are fetched before the staging barriers so their latency hides behind the LDS traffic.
 #include "common.h"
 #include <stdlib.h>
 
-#define BM 128
 #define BN 128
 #define CS_LD 132  // fp32 staging row pitch
 
@@ -56,17 +58,32 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool CONV, int BK, int NSTAGE, int WPS>
-__global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
+// exact-erf GELU to fp16 accuracy without libm's branches: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7),
+// one v_rcp + one v_exp + 7 FMAs.  (diffusers GEGLU uses F.gelu(approximate='none').)
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+template <bool CONV, int BK, int NSTAGE, int WM, int WPS>
+__global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
+  constexpr int BM = WM * 64;
+  constexpr int NW = WM * 2;               // waves
+  constexpr int T = NW * 64;               // threads
   constexpr int ROWB = BK * 2;             // bytes per tile row
   constexpr int SLOTS = BK / 8;            // 16-B slots per row
   constexpr int RPI = 1024 / ROWB;         // rows covered by one wave-wide DMA instruction
-  constexpr int IPW = (BM / RPI) / 4;      // DMA instructions per wave per operand per tile
-  constexpr int OPB = BM * ROWB;           // bytes of one operand tile
-  constexpr int STAGE = 2 * OPB;
-  constexpr int G = 2 * IPW;               // DMA instructions per thread per tile
+  constexpr int IPA = (BM / RPI) / NW;     // DMA instructions per wave per tile, A operand
+  constexpr int IPB = (BN / RPI) / NW;     // ... W operand
+  constexpr int OPA = BM * ROWB;           // bytes of the A tile
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int G = IPA + IPB;             // DMA instructions per wave per tile
   constexpr int SW_SHIFT = BK == 32 ? 2 : 1;
   constexpr int SW_MASK = SLOTS - 1;
+  static_assert(IPA >= 1 && IPB >= 1, "tile too small for the wave count");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Cs = reinterpret_cast<float*>(smem);
 
@@ -88,17 +105,15 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
 
   // ---- per-lane DMA source coordinates
   const int lrow = lane / SLOTS, pslot = lane % SLOTS;
-  const half_t* a_src[IPW];
-  const half_t* w_src[IPW];
-  int a_oy[IPW], a_ox[IPW];
-  bool a_ok[IPW];
+  const half_t* a_src[IPA];
+  const half_t* w_src[IPB];
+  int a_oy[IPA], a_ox[IPA];
 #pragma unroll
-  for (int j = 0; j < IPW; ++j) {
-    const int row = (wave * IPW + j) * RPI + lrow;
+  for (int j = 0; j < IPA; ++j) {
+    const int row = (wave * IPA + j) * RPI + lrow;
     const int lslot = pslot ^ ((row >> SW_SHIFT) & SW_MASK);
     const int m = m0 + row;
-    a_ok[j] = m < p.M;
-    const int mm = a_ok[j] ? m : p.M - 1;
+    const int mm = m < p.M ? m : p.M - 1;
     if (CONV) {
       const int hw = p.Hout * p.Wout;
       const int b = mm / hw, rem = mm - b * hw;
@@ -110,6 +125,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
       a_oy[j] = a_ox[j] = 0;
       a_src[j] = p.A + (size_t)mm * p.lda + lslot * 8;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < IPB; ++j) {
+    const int row = (wave * IPB + j) * RPI + lrow;
+    const int lslot = pslot ^ ((row >> SW_SHIFT) & SW_MASK);
     const int n = n0 + row;
     w_src[j] = p.W + (size_t)(n < p.N ? n : p.N - 1) * p.K + lslot * 8;
   }
@@ -117,13 +137,14 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
 
   auto issue_tile = [&](int kt, int stage) {
     const int k0 = kt * BK;
-    char* base = smem + stage * STAGE + (wave * IPW) * 1024;
+    char* sa = smem + stage * STAGE + (wave * IPA) * 1024;
+    char* sw = smem + stage * STAGE + OPA + (wave * IPB) * 1024;
     if (CONV) {
       const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
       const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
 #pragma unroll
-      for (int j = 0; j < IPW; ++j) {
+      for (int j = 0; j < IPA; ++j) {
         // branch-free: the element offset is computed for every lane (24-bit multiplies), then the pointer is swapped
         // for the zero page where the tap falls outside the image
         const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
@@ -132,14 +153,14 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
         asm volatile("" : "+v"(off));
         const half_t* src = a_src[j] + off;
         src = ok ? src : zero_src;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + j * 1024), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < IPW; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + k0), (lptr_t)(base + j * 1024), 16, 0, 0);
+      for (int j = 0; j < IPA; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + k0), (lptr_t)(sa + j * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + k0), (lptr_t)(base + OPB + j * 1024), 16, 0, 0);
+    for (int j = 0; j < IPB; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + k0), (lptr_t)(sw + j * 1024), 16, 0, 0);
   };
 
   floatx16 acc[2][2];
@@ -161,21 +182,26 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
   for (int i = 0; i < 2; ++i) {
     const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
     a_off[i] = ra * ROWB;
-    b_off[i] = OPB + rb * ROWB;
+    b_off[i] = OPA + rb * ROWB;
     a_sw[i] = (ra >> SW_SHIFT) & SW_MASK;
     b_sw[i] = (rb >> SW_SHIFT) & SW_MASK;
   }
 
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most (tiles still allowed in flight) x G of this wave's DMAs are outstanding
-    const int ahead = nk - 1 - kt;  // tiles issued after kt
+    // tile kt has landed once at most min(NSTAGE-2, tiles issued after kt) x G of this wave's DMAs are outstanding
+    const int ahead = nk - 1 - kt;
+    if (NSTAGE == 1) {
+      // single buffer (occupancy flavour): other workgroups on the CU cover this one's exposed load latency
+      if (kt > 0) __builtin_amdgcn_s_barrier();
+      issue_tile(kt, 0);
+    }
     if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * G>();
     else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<G>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     // every wave has finished tile kt-1 -> its ring slot can be refilled with tile kt+NSTAGE-1
-    if (kt + NSTAGE - 1 < nk) {
+    if (NSTAGE > 1 && kt + NSTAGE - 1 < nk) {
       int st = stage + NSTAGE - 1;
       if (st >= NSTAGE) st -= NSTAGE;
       issue_tile(kt + NSTAGE - 1, st);
@@ -200,18 +226,21 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
   // ---- epilogue: accumulators -> LDS (fp32, 64 rows per pass) -> coalesced rows
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int Nout = p.act == ACT_GEGLU ? p.N >> 1 : p.N;
+  constexpr int RP = T / 16;      // rows per sweep of the plain epilogue (16 threads x 8 columns per row)
+  constexpr int NI = 64 / RP;     // sweeps per 64-row pass
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < WM; ++pass) {
+    const int mp = m0 + pass * 64;
     // residual rows of this pass (plain epilogue): issue the loads BEFORE the staging barriers so that their HBM
     // latency overlaps the accumulator -> LDS traffic
-    half8_t rv[4];
-    bool rvec[4];
+    half8_t rv[NI];
+    bool rvec[NI];
     {
       const int n = n0 + (tid & 15) * 8;
       const bool nvec = (p.N - n) >= 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + pass * 64 + (tid >> 4) + 16 * i;
+      for (int i = 0; i < NI; ++i) {
+        const int m = mp + (tid >> 4) + RP * i;
         rvec[i] = false;
         if (p.residual && m < p.M && nvec) {
           const half_t* rs = p.residual + (size_t)m * p.ldr + n;
@@ -236,7 +265,6 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
           }
     }
     __syncthreads();
-    const int mp = m0 + pass * 64;
 
     if (p.transpose_out) {
       // out[n][m]: thread owns one column n and 8 consecutive rows -> one 16-B store along m
@@ -245,8 +273,8 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
       if (n < p.N) {
         const float bv = p.bias ? (float)p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rc = (tid >> 7) + 2 * i;
+        for (int i = 0; i < 8 / (T / 128); ++i) {
+          const int rc = (tid >> 7) + (T / 128) * i;
           const int m = mp + rc * 8;
           if (m >= p.M) continue;
           half8_t o;
@@ -278,15 +306,15 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 3) + 32 * i;
+      for (int i = 0; i < 64 / (T / 8); ++i) {
+        const int row = (tid >> 3) + (T / 8) * i;
         const int m = mp + row;
         if (m >= p.M || nout0 >= Nout) continue;
         half8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float h = Cs[row * CS_LD + hcol + j] + bh[j], g = Cs[row * CS_LD + gcol + j] + bg[j];
-          o[j] = (half_t)(h * gelu_erf_f(g));
+          o[j] = (half_t)(h * gelu_fast(g));
         }
         *reinterpret_cast<half8_t*>(p.C + (size_t)m * p.ldc + nout0) = o;
       }
@@ -310,8 +338,8 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + 16 * i;
+      for (int i = 0; i < NI; ++i) {
+        const int row = (tid >> 4) + RP * i;
         const int m = mp + row;
         if (m >= p.M || nv <= 0) continue;
         float v[8];
@@ -362,48 +390,58 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(GemmParams p) {
   }
 }
 
-// ring geometry variants (MD_GEMM_VARIANT env var, read once; default 0):
+// ---- variants (MD_GEMM_VARIANT / MD_CONV_VARIANT env vars select the 128-row flavour, MD_GEMM_BIG the 256-row one) ----
 //   0: BK=32 x 4 stages = 64 KiB  -> 2 workgroups/CU, three 16-KiB tiles in flight each
 //   1: BK=32 x 3 stages = 48 KiB  -> 3 workgroups/CU, two tiles in flight each
-//   2: BK=64 x 2 stages = 64 KiB  -> 2 workgroups/CU, one 32-KiB tile in flight each
-//   3: BK=64 x 3 stages = 96 KiB  -> 1 workgroup/CU, two 32-KiB tiles in flight
+//   2: BK=64 x 2 stages = 64 KiB  -> 2 workgroups/CU, one 32-KiB tile in flight each      (default for 3x3 convs)
+//   6: BK=64 x 1 stage  = 34 KiB  -> 3 workgroups/CU (<= 168 registers), load latency covered by the other workgroups
+//      (default for Linear GEMMs: measured best on every config-2 shape, 856 TF at 8192^3)
+//   7: BK=32 x 1 stage  = 34 KiB  -> 4 workgroups/CU (<= 128 registers)
+//   big: 256x128, BK=64 x 3 stages = 144 KiB, 8 waves, 1 workgroup/CU, two 48-KiB tiles in flight
 static constexpr size_t kCsBytes = (size_t)64 * CS_LD * 4;
-template <int BK, int NSTAGE>
+template <int BK, int NSTAGE, int WM>
 static constexpr size_t gemm_smem() {
-  return ((size_t)NSTAGE * 2 * BM * BK * 2 > kCsBytes) ? (size_t)NSTAGE * 2 * BM * BK * 2 : kCsBytes;
+  return ((size_t)NSTAGE * (WM * 64 + BN) * BK * 2 > kCsBytes) ? (size_t)NSTAGE * (WM * 64 + BN) * BK * 2 : kCsBytes;
 }
 
-template <bool CONV, int BK, int NSTAGE, int WPS = 1>
-static void launch_variant(const GemmParams& p, hipStream_t stream) {
+template <bool CONV, int BK, int NSTAGE, int WM = 2, int WPS = 1>
+static void launch_variant(GemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr size_t smem = gemm_smem<BK, NSTAGE>();
+  constexpr size_t smem = gemm_smem<BK, NSTAGE, WM>();
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WM, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WPS>), dim3(p.tiles_total), dim3(256), smem, stream, p);
+  p.tiles_n = cdiv(p.N, BN);
+  p.tiles_total = cdiv(p.M, WM * 64) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WM, WPS>), dim3(p.tiles_total), dim3(WM * 128), smem, stream, p);
 }
 
-static int gemm_variant(bool conv) {
-  // measured on MI355X at the config-2 shapes (tools/bench_kernels.py): the skinny-K Linear GEMMs like 3 workgroups
-  // per CU (variant 1); the 3x3 convs (K = 2880..23040) like the 64-wide K step (variant 2)
-  static int v[2] = {-1, -1};
-  if (v[conv] < 0) {
-    const char* e = getenv(conv ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT");
-    v[conv] = e ? atoi(e) : (conv ? 2 : 1);
-    if (v[conv] < 0 || v[conv] > 5) v[conv] = conv ? 2 : 1;
-  }
-  return v[conv];
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 template <bool CONV>
-static void launch_any(const GemmParams& p, hipStream_t stream) {
-  switch (gemm_variant(CONV)) {
+static void launch_any(GemmParams& p, hipStream_t stream) {
+  static int variant = -1, big = -1;
+  if (variant < 0) {
+    variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
+    big = env_int("MD_GEMM_BIG", 0);
+  }
+  // the 256-row tile needs enough work to fill 256 CUs with ONE workgroup each and a deep K loop to amortise its ring
+  const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
+  if (big && tiles256 >= 512 && p.K >= 512) {
+    static int dbg = env_int("MD_GEMM_DEBUG", 0);
+    if (dbg) { fprintf(stderr, "[md_gemm] 256x128 tile: M=%d N=%d K=%d conv=%d\n", p.M, p.N, p.K, (int)CONV); dbg = 0; }
+    launch_variant<CONV, 64, 3, 4>(p, stream);
+    return;
+  }
+  switch (variant) {
     case 0: launch_variant<CONV, 32, 4>(p, stream); break;
     case 1: launch_variant<CONV, 32, 3>(p, stream); break;
-    case 3: launch_variant<CONV, 64, 3>(p, stream); break;
-    case 4: launch_variant<CONV, 32, 2, 4>(p, stream); break;
-    case 5: launch_variant<CONV, 32, 3, 3>(p, stream); break;
+    case 6: launch_variant<CONV, 64, 1, 2, 3>(p, stream); break;
+    case 7: launch_variant<CONV, 32, 1, 2, 4>(p, stream); break;
     default: launch_variant<CONV, 64, 2>(p, stream); break;
   }
 }
@@ -418,8 +456,6 @@ static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
   }
   if (p.transpose_out) MD_CHECK_ARG(!p.residual && !p.rowadd && p.act == ACT_NONE, "md_gemm: transposed store supports bias only");
   if (p.rowadd) MD_CHECK_ARG(p.rows_per_group > 0, "md_gemm: rows_per_group must be > 0 with rowadd");
-  p.tiles_n = cdiv(p.N, BN);
-  p.tiles_total = cdiv(p.M, BM) * p.tiles_n;
   if (conv)
     launch_any<true>(p, stream);
   else
