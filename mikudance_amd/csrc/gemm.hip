@@ -442,6 +442,7 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
     case 1: launch_variant<CONV, 32, 3>(p, stream); break;
     case 6: launch_variant<CONV, 64, 1, 2, 3>(p, stream); break;
     case 7: launch_variant<CONV, 32, 1, 2, 4>(p, stream); break;
+    case 8: launch_variant<CONV, 64, 1, 2, 4>(p, stream); break;
     default: launch_variant<CONV, 64, 2>(p, stream); break;
   }
 }

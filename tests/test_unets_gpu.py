@@ -101,3 +101,35 @@ def test_run_to_run_bitwise_determinism(small):
     args = (t["in.latents"][:, :, :4].cuda().half(), t["in.ref_latents"][:, :4].cuda().half(), t["in.embeds"].cuda().half(), 2, 3.5)
     a, b = pipe.denoise(*args), pipe.denoise(*args)
     assert torch.equal(a, b)
+
+
+def test_long_clip_windows_f30_vs_oracle(small):
+    """BASELINE config 5 in miniature: F=40 frames -> wrapping windows of 30 frames (60-frame UNet batches, temporal
+    attention over 30 frames, overlap averaging through noise_pred / counter)."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    from mikudance_amd.synth import synth_inputs
+    lat, rl, emb = synth_inputs(40, 16, 16, ctx_len=5, ctx_dim=64, seed=7)
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 2, guidance_scale=3.5, context_frames=30, context_stride=1,
+                              context_overlap=8, reduced=True)
+    out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5, context_frames=30, context_stride=1,
+                       context_overlap=8)
+    assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+    with pytest.raises(ValueError):            # 33 > positional-encoding table (quirk 6)
+        pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 1, 3.5, context_frames=33)
+
+
+def test_config1_full_width_vs_oracle():
+    """BASELINE configs[0] geometry (256x256 -> 32x32 latents, 4 frames, CFG) with the FULL-WIDTH SD-1.5 UNets
+    (head dims 40/80/160, 320..1280 channels, 257x768 context): 2 DDIM steps on the GPU vs the fp32 CPU oracle."""
+    from mikudance_amd.synth import synth_inputs
+    full = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    ref, den, ref_sd, den_sd = build_models(geom=full)
+    lat, rl, emb = synth_inputs(4, 32, 32, ctx_len=257, ctx_dim=768, seed=100)
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5)
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 2, guidance_scale=3.5, reduced=True)
+    r, c = rel_l2(out.float(), want), cosine(out.float(), want)
+    assert r < 3e-2 and c > 0.999, (r, c)
