@@ -125,7 +125,10 @@ def main():
                         frac=achieved / (PEAK_HBM / 1e9), launches=dom["count"], avg_ms=dom_ms, traffic=None)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        roofline["traffic"] = json.load(open(pmc)).get(dom_label.split(" ")[0])
+        rec = json.load(open(pmc)).get(dom_label)
+        roofline["traffic"] = rec["hbm_bytes_corrected"] if rec else None   # HBM-side bytes per launch (profiles/pmc_traffic.json)
+        if rec:
+            roofline["algorithmic_bytes"] = rec["algorithmic_bytes"]
 
     frames_total = args.frames * args.steps * world
     value = frames_total / elapsed

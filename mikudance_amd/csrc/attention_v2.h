@@ -66,9 +66,25 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  // XCD-aware mapping: workgroup id L runs on XCD L % 8 (observed dispatch order, speed only).  All q-blocks of one
+  // (batch, head) pair go to ONE XCD so that its K / V^T tiles are fetched into a single private L2 instead of all
+  // eight (measured: 8x the algorithmic K/V bytes at the fabric otherwise).
+  const int nqb = (p.Lq + 128 * QT - 1) / (128 * QT);
+  int pair, qblk;
+  {
+    const int L = blockIdx.x, npair = p.B * p.H;
+    if ((npair & 7) == 0) {
+      const int xcd = L & 7, slot = L >> 3;
+      pair = xcd + 8 * (slot / nqb);
+      qblk = slot - (slot / nqb) * nqb;
+    } else {
+      pair = L / nqb;
+      qblk = L - pair * nqb;
+    }
+  }
+  const int b = pair / p.H, h = pair - b * p.H;
   const int kb = p.kv_index ? p.kv_index[b] : b;
-  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
+  const int q0 = qblk * (128 * QT) + wave * (32 * QT);
   const int lk8 = (p.Lk + 7) & ~7;
 
   const half_t* Kb = p.K + (size_t)kb * p.kv_stride * p.ldk + h * D;
@@ -270,7 +286,7 @@ static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<D, NST, QT, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  dim3 grid(cdiv(p.Lq, 128 * QT), p.H, p.B);
+  dim3 grid(cdiv(p.Lq, 128 * QT) * p.H * p.B);
   hipLaunchKernelGGL((attn2_kernel<D, NST, QT, WPS>), grid, dim3(256), smem, stream, p);
   MD_CHECK_LAUNCH("md_attention_fwd");
   return MD_OK;

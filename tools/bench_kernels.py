@@ -47,7 +47,7 @@ def main(which):
             ms = timeit(lambda: ops.conv3x3(x, w, Cout, bias=b, out=o))
             out[f"conv {B}x{H}x{H} {Cin}->{Cout}"] = (ms, 2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9)
     if "attn" in which:
-        for B, L, D in [(8, 9216, 40), (32, 2304, 80), (32, 576, 160)]:
+        for B, L, D in [(8, 9216, 40), (32, 9216, 40), (32, 2304, 80), (32, 576, 160)]:
             C = 8 * D
             q, k, vt = rnd(B * L, C), rnd(B * L, C), rnd(C, B * L)
             o = torch.empty((B * L, C), device=dev, dtype=torch.float16)
