@@ -18,6 +18,7 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   const half_t* base = x + (size_t)b * HW * C + cc * 8;
+#pragma unroll 4
   for (int p = p0 + r; p < p1; p += R) {
     const half8_t v = *reinterpret_cast<const half8_t*>(base + (size_t)p * C);
 #pragma unroll
@@ -80,6 +81,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
   }
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
   const size_t base = (size_t)b * HW * C + cc * 8;
+#pragma unroll 4
   for (int p = p0 + r; p < p1; p += R) {
     const half8_t v = *reinterpret_cast<const half8_t*>(x + base + (size_t)p * C);
     half8_t o;
@@ -122,65 +124,101 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave per row, row held in registers (C <= 8*64*MAXC).
+// One wave owns LN_R consecutive rows held in registers (C <= 8*64*MAXC): the loads of all LN_R rows are issued before
+// the first reduction, which quadruples the bytes in flight per wave (a single 640-byte row per wave left the kernel
+// latency bound at ~3.3 TB/s).
+#define LN_R 4
 #define LN_MAXC 4
+template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, half_t* __restrict__ y2,
                                                         const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
                                                         const half_t* __restrict__ add, int M, int C, float eps, int add_mode, int add_row_begin,
                                                         int rows_per_frame, int frames) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_R;
+  if (row0 >= M) return;
   const int cch = C >> 3;
-  float v[LN_MAXC][8];
-  float sum = 0.f;
+  float v[LN_R][MAXC][8];
 #pragma unroll
-  for (int k = 0; k < LN_MAXC; ++k) {
-    const int c = lane + k * 64;
-    if (c < cch) {
-      const half8_t h = *reinterpret_cast<const half8_t*>(x + (size_t)row * C + c * 8);
+  for (int r = 0; r < LN_R; ++r) {
+    const int row = min(row0 + r, M - 1);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[k][e] = (float)h[e];
-        sum += v[k][e];
-      }
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = lane + k * 64;
+      half8_t h = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < cch) h = *reinterpret_cast<const half8_t*>(x + (size_t)row * C + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[r][k][e] = (float)h[e];
     }
   }
-  const float mu = wave_sum(sum) / (float)C;
-  float sq = 0.f;
+  half8_t g[MAXC], bt[MAXC];
 #pragma unroll
-  for (int k = 0; k < LN_MAXC; ++k) {
+  for (int k = 0; k < MAXC; ++k) {
     const int c = lane + k * 64;
     if (c < cch) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[k][e] - mu;
-        sq += d * d;
-      }
+      g[k] = *reinterpret_cast<const half8_t*>(gamma + c * 8);
+      bt[k] = *reinterpret_cast<const half8_t*>(beta + c * 8);
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-  const half_t* addp = nullptr;
-  if (add_mode == 1 && row >= add_row_begin) addp = add + (size_t)(row - add_row_begin) * C;  // bank rows
-  if (add_mode == 2) addp = add + (size_t)((row / rows_per_frame) % frames) * C;            // positional encoding of the frame
+  float mu[LN_R], rstd[LN_R];
 #pragma unroll
-  for (int k = 0; k < LN_MAXC; ++k) {
-    const int c = lane + k * 64;
-    if (c < cch) {
-      const half8_t g = *reinterpret_cast<const half8_t*>(gamma + c * 8);
-      const half8_t bt = *reinterpret_cast<const half8_t*>(beta + c * 8);
-      half8_t o;
+  for (int r = 0; r < LN_R; ++r) {
+    float sum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[k][e] - mu) * rstd * (float)g[e] + (float)bt[e]);
-      *reinterpret_cast<half8_t*>(y + (size_t)row * C + c * 8) = o;
-      if (y2) {
-        half8_t o2 = o;
-        if (addp) {
-          const half8_t a = *reinterpret_cast<const half8_t*>(addp + c * 8);
+    for (int k = 0; k < MAXC; ++k)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o2[e] = (half_t)((float)o[e] + (float)a[e]);  // fp16 n + fp16 bank, one rounding
+      for (int e = 0; e < 8; ++e) sum += v[r][k][e];      // lanes beyond the row hold zeros
+    mu[r] = sum;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) mu[r] += __shfl_xor(mu[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < LN_R; ++r) {
+    mu[r] /= (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      if (lane + k * 64 < cch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[r][k][e] - mu[r];
+          sq += d * d;
         }
-        *reinterpret_cast<half8_t*>(y2 + (size_t)row * C + c * 8) = o2;
+      }
+    }
+    rstd[r] = sq;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < LN_R; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const float rs = rsqrtf(rstd[r] / (float)C + eps);
+    const half_t* addp = nullptr;
+    if (add_mode == 1 && row >= add_row_begin) addp = add + (size_t)(row - add_row_begin) * C;  // bank rows
+    if (add_mode == 2) addp = add + (size_t)((row / rows_per_frame) % frames) * C;            // positional encoding of the frame
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = lane + k * 64;
+      if (c < cch) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[r][k][e] - mu[r]) * rs * (float)g[k][e] + (float)bt[k][e]);
+        *reinterpret_cast<half8_t*>(y + (size_t)row * C + c * 8) = o;
+        if (y2) {
+          half8_t o2 = o;
+          if (addp) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(addp + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = (half_t)((float)o[e] + (float)a[e]);  // fp16 n + fp16 bank, one rounding
+          }
+          *reinterpret_cast<half8_t*>(y2 + (size_t)row * C + c * 8) = o2;
+        }
       }
     }
   }
@@ -191,8 +229,16 @@ extern "C" int md_layernorm_f16(const void* x, void* y, void* y2, const void* ga
   MD_CHECK_ARG(C % 8 == 0 && C <= 8 * 64 * LN_MAXC, "md_layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXC);
   MD_CHECK_ARG(add_mode == 0 || (add != nullptr && y2 != nullptr), "md_layernorm: add_mode needs add and y2");
   MD_CHECK_ARG(add_mode != 2 || (rows_per_frame > 0 && frames > 0), "md_layernorm: add_mode 2 needs rows_per_frame and frames");
-  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (half_t*)y2, (const half_t*)gamma,
-                     (const half_t*)beta, (const half_t*)add, M, C, eps, add_mode, add_row_begin, rows_per_frame, frames);
+  const dim3 grid(cdiv(M, 4 * LN_R)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LN_LAUNCH(MC)                                                                                                                           \
+  hipLaunchKernelGGL(layernorm_kernel<MC>, grid, block, 0, st, (const half_t*)x, (half_t*)y, (half_t*)y2, (const half_t*)gamma, (const half_t*)beta, \
+                     (const half_t*)add, M, C, eps, add_mode, add_row_begin, rows_per_frame, frames)
+  if (C <= 512) LN_LAUNCH(1);
+  else if (C <= 1024) LN_LAUNCH(2);
+  else if (C <= 1536) LN_LAUNCH(3);
+  else LN_LAUNCH(4);
+#undef LN_LAUNCH
   MD_CHECK_LAUNCH("md_layernorm");
   return MD_OK;
 }

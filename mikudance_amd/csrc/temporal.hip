@@ -33,26 +33,28 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   const long pg = (long)(blockIdx.x / ngrp) * p.PB;  // first global (b, pixel) of this workgroup
   const long npix = (long)p.NB * p.HW;
   const int col0 = grp * CW;
-  half_t* Ks = reinterpret_cast<half_t*>(smem);
-  half_t* Vs = Ks + (size_t)p.F * p.PB * CW;
-
-  // ---- stage K and V: chunk id -> (frame j, pixel pl, 16-B column chunk)
+  // ---- stage K and V by direct-to-LDS DMA: chunk id c -> (frame j, pixel pl, 16-B column chunk) lands at LDS
+  // offset 16*c, i.e. the LDS image is lane linear, so every wave issues all its DMAs back to back (no VGPR staging,
+  // maximum memory-level parallelism) and waits once.  Each region is padded to a whole number of 1-KiB DMA rows.
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
   const int nchunk = p.F * p.PB * cw8;
-  for (int c = t; c < nchunk; c += blockDim.x) {
-    const int cc = c % cw8;
-    const int pl = (c / cw8) % p.PB;
-    const int j = c / (cw8 * p.PB);
-    const long gp = pg + pl;
-    half8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (gp < npix) {
-      const int b = (int)(gp / p.HW), pix = (int)(gp % p.HW);
-      const size_t row = ((size_t)b * p.F + j) * p.HW + pix;
-      kv = *reinterpret_cast<const half8_t*>(p.K + row * p.ldk + col0 + cc * 8);
-      vv = *reinterpret_cast<const half8_t*>(p.V + row * p.ldv + col0 + cc * 8);
-    }
-    *reinterpret_cast<half8_t*>(Ks + (size_t)c * 8) = kv;
-    *reinterpret_cast<half8_t*>(Vs + (size_t)c * 8) = vv;
+  const int region = ((nchunk * 16 + 1023) >> 10) << 10;
+  half_t* Ks = reinterpret_cast<half_t*>(smem);
+  half_t* Vs = reinterpret_cast<half_t*>(smem + region);
+  for (int c = t; c < (region >> 4); c += blockDim.x) {
+    const int cl = min(c, nchunk - 1);
+    const int cc = cl % cw8;
+    const int pl = (cl / cw8) % p.PB;
+    const int j = cl / (cw8 * p.PB);
+    const long gp = min(pg + pl, npix - 1);
+    const int b = (int)(gp / p.HW), pix = (int)(gp % p.HW);
+    const size_t row = ((size_t)b * p.F + j) * p.HW + pix;
+    const int cbase = __builtin_amdgcn_readfirstlane(c) << 4;    // lane 0 of the wave: c - lane
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.K + row * p.ldk + col0 + cc * 8), (lptr_t)(smem + cbase), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.V + row * p.ldv + col0 + cc * 8), (lptr_t)(smem + region + cbase), 16, 0, 0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int hl = t % p.HG;
@@ -69,48 +71,52 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   const int fstride = p.PB * CW;
   const int nch = p.D >> 3;
 
+  // No per-frame branches: frames beyond F are clamped to F-1 for the loads and masked arithmetically afterwards, so the
+  // compiler can batch all FMAX ds_read_b128 of a chunk ahead of the dot products (a branch per frame serialised one
+  // LDS round trip per frame).
+  int joff[FMAX];
+#pragma unroll
+  for (int j = 0; j < FMAX; ++j) joff[j] = min(j, p.F - 1) * fstride;
   float s[FMAX];
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) s[j] = 0.f;
   for (int c = 0; c < nch; ++c) {
     const half8_t q8 = *reinterpret_cast<const half8_t*>(qp + c * 8);
+    half8_t k8[FMAX];
+#pragma unroll
+    for (int j = 0; j < FMAX; ++j) k8[j] = *reinterpret_cast<const half8_t*>(kp + joff[j] + c * 8);
 #pragma unroll
     for (int j = 0; j < FMAX; ++j) {
-      if (j < p.F) {
-        const half8_t k8 = *reinterpret_cast<const half8_t*>(kp + j * fstride + c * 8);
-        float a = s[j];
+      float a = s[j];
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) a = __builtin_amdgcn_fdot2(half2_t{q8[e], q8[e + 1]}, half2_t{k8[e], k8[e + 1]}, a, false);
-        s[j] = a;
-      }
+      for (int e = 0; e < 8; e += 2) a = __builtin_amdgcn_fdot2(half2_t{q8[e], q8[e + 1]}, half2_t{k8[j][e], k8[j][e + 1]}, a, false);
+      s[j] = a;
     }
   }
   float m = -1.0e30f;
 #pragma unroll
-  for (int j = 0; j < FMAX; ++j)
-    if (j < p.F) m = fmaxf(m, s[j]);
+  for (int j = 0; j < FMAX; ++j) {
+    s[j] = j < p.F ? s[j] : -1.0e30f;
+    m = fmaxf(m, s[j]);
+  }
   float l = 0.f;
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) {
-    if (j < p.F) {
-      s[j] = __builtin_amdgcn_exp2f((s[j] - m) * p.scale_log2);
-      l += s[j];
-    } else {
-      s[j] = 0.f;
-    }
+    s[j] = __builtin_amdgcn_exp2f((s[j] - m) * p.scale_log2);   // masked frames: exp2(-huge) = 0
+    l += s[j];
   }
   const float inv = 1.f / l;
   for (int c = 0; c < nch; ++c) {
+    half8_t v8[FMAX];
+#pragma unroll
+    for (int j = 0; j < FMAX; ++j) v8[j] = *reinterpret_cast<const half8_t*>(vp + joff[j] + c * 8);
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < FMAX; ++j) {
-      if (j < p.F) {
-        const half8_t v8 = *reinterpret_cast<const half8_t*>(vp + j * fstride + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += s[j] * (float)v8[e];
-      }
+      for (int e = 0; e < 8; ++e) o[e] += s[j] * (float)v8[j][e];
     }
     half8_t ov;
 #pragma unroll
@@ -149,7 +155,8 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
   p.PB = PB; p.HG = HG;
   p.scale_log2 = scale * 1.4426950408889634f;
   const int threads = ((PB * HG * F + 63) / 64) * 64;
-  const size_t smem = (size_t)4 * F * PB * HG * D;
+  const size_t region = (((size_t)2 * F * PB * HG * D + 1023) >> 10) << 10;   // K (and V) image, whole 1-KiB DMA rows
+  const size_t smem = 2 * region;
   const int grid = cdiv((long)NB * HW, PB) * (H / HG);
   hipStream_t st = (hipStream_t)stream;
   if (F <= 4) launch_temporal<4>(p, grid, threads, smem, st);
