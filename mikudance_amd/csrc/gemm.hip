@@ -215,10 +215,14 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
         af[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
         bf[i] = *reinterpret_cast<const half8_t*>(sb + b_off[i] + (((s * 2 + fhi) ^ b_sw[i]) << 4));
       }
+      // the workgroups sharing this CU sit in different phases (DMA issue / LDS reads / epilogue): favour whoever has
+      // its operands ready for the matrix pipe (guide T5)
+      if (!CONV) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      if (!CONV) __builtin_amdgcn_s_setprio(0);
     }
     if (++stage == NSTAGE) stage = 0;
   }
