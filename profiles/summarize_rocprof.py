@@ -25,7 +25,7 @@ def main(db, out, bench=None):
         lines += ["", "## dominant kernel (bench.py `roofline`)", "", f"bench.py: `{roof['kernel']}` avg {roof['avg_ms']:.3f} ms over {roof['launches']} launches "
                   f"(HIP events), {roof['achieved']:.1f} {roof['unit']} = {100 * roof['frac']:.1f} % of peak", ""]
         fam = roof["kernel"].split(" ")[0]
-        pat = {"attention": "attn_kernel<%s>" % roof["kernel"].split("D=")[1].split(" ")[0] if "D=" in roof["kernel"] else "attn_kernel",
+        pat = {"attention": "attn%%_kernel<%s," % roof["kernel"].split("D=")[1].split(" ")[0] if "D=" in roof["kernel"] else "attn",
                "gemm": "gemm_kernel<false>", "conv3x3": "gemm_kernel<true>", "temporal_attention": "temporal_attn_kernel",
                "groupnorm": "gn_", "layernorm": "layernorm_kernel"}[fam]
         durs = sorted(r[0] / 1e6 for r in c.execute("select end-start from kernels where name like ?", (f"%{pat}%",)))
