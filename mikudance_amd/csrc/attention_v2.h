@@ -2,7 +2,7 @@
 // are multiples of 8; the cross-attention context is padded to a multiple of 8 tokens).  Same math and layouts as
 // attn_kernel<D> (attention.hip), restructured around what limited that kernel on MI355X (VALU work and stalls, not MFMA):
 //
-//  * K and V^T tiles (64 keys) go HBM/L2 -> LDS by direct-to-LDS DMA into a 3-deep ring with counted vmcnt waits and one
+//  * K and V^T tiles (64 keys) go HBM/L2 -> LDS by direct-to-LDS DMA into a 2-deep ring with counted vmcnt waits and one
 //    raw s_barrier per tile (no VGPR staging, two tiles in flight).
 //  * The K rows fed to MFMA row index i are the keys kappa(i) = i with bits 2 and 3 swapped.  With that choice the
 //    32x32 C layout of S^T leaves every lane holding, per 16-key step, EIGHT CONSECUTIVE keys, so the P fragment pairs
@@ -117,10 +117,44 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 
   // ---- DMA: instruction q of a tile (q < NKI: K image, else V^T image) is issued by wave q % 4
   const int n_mine = (NI - wave + 3) / 4;
-  auto issue_tile = [&](int j0, int stage) {
-    char* sb = smem + stage * STAGE;
+  // per-lane source of tile 0 and the per-tile byte step (K: 64 rows down, V^T: 64 keys = 128 bytes to the right), so that a
+  // full tile costs one 64-bit add per DMA; only the ragged last tile recomputes clamped addresses
+  constexpr int NQ = (NI + 3) / 4;
+  const char* src0[NQ];
+  long step[NQ];
 #pragma unroll
-    for (int qi = 0; qi < (NI + 3) / 4; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int q = qi * 4 + wave;
+    src0[qi] = reinterpret_cast<const char*>(Kb);
+    step[qi] = 0;
+    if (q < NKI) {
+      const int o = q * 1024 + lane * 16;
+      const int row = o / KROWB, cb = o - row * KROWB;
+      src0[qi] = reinterpret_cast<const char*>(Kb + (size_t)row * p.ldk) + cb;
+      step[qi] = (long)A2_KT * p.ldk * 2;
+    } else if (q < NI) {
+      const int qv = q - NKI;
+      const int o = qv * 1024 + lane * 16;
+      const int dv = o >> 7, ps = (o & 127) >> 4;
+      const int ls = ps ^ ((dv >> 1) & 7);
+      src0[qi] = reinterpret_cast<const char*>(Vb + (size_t)dv * p.ldvt + ls * 8);
+      step[qi] = A2_KT * 2;
+    }
+  }
+  auto issue_tile = [&](int it_, int stage) {
+    char* sb = smem + stage * STAGE;
+    const int j0 = it_ * A2_KT;
+    if (j0 + A2_KT <= p.Lk) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        const int q = qi * 4 + wave;
+        if (q < NI)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src0[qi] + it_ * step[qi]), (lptr_t)(sb + (q < NKI ? q * 1024 : KBYTES + (q - NKI) * 1024)), 16, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
       const int q = qi * 4 + wave;
       if (q < NKI) {
         const int o = q * 1024 + lane * 16;
@@ -153,7 +187,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < ntiles) issue_tile(s * A2_KT, s);
+    if (s < ntiles) issue_tile(s, s);
 
   // K row read by MFMA row index ql: key kappa(ql) = ql with bits 2 and 3 swapped
   const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1);
@@ -167,7 +201,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     if (it + NST - 1 < ntiles) {
       int st = stage + NST - 1;
       if (st >= NST) st -= NST;
-      issue_tile((it + NST - 1) * A2_KT, st);
+      issue_tile(it + NST - 1, st);
     }
     const char* ks = smem + stage * STAGE;
     const char* vs = ks + KBYTES;
@@ -185,8 +219,14 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2);
+#ifdef A2_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int u = 0; u < QT; ++u) s[u][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][k], s[u][sub], 0, 0, 0);
+#ifdef A2_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
     // register r of sub-tile `sub` in lane half `hi` holds key j0 + sub*32 + 16*(r>>3) + 8*hi + (r&7)
@@ -238,8 +278,14 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const half8_t vf = *reinterpret_cast<const half8_t*>(vs + (t * 32 + ql) * 128 + (((k * 2 + hi) ^ vsw) << 4));
+#ifdef A2_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int u = 0; u < QT; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][k], o[u][t], 0, 0, 0);
+#ifdef A2_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
     if (++stage == NST) stage = 0;
@@ -276,9 +322,15 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 
 template <int D, int QT>
 static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
-  constexpr int NST = D > 40 ? 2 : 3;
+  constexpr int NST = 2;   // same-box A/B on MI355X: a 2-deep ring beats 3-deep by ~3 % at D = 40 (less LDS, same overlap)
   // occupancy targets that fit without spilling: D <= 40 -> 4 waves/SIMD (<= 128 registers), D <= 80 -> 3 (<= 168)
+#if defined(A2_WPS6)
+  constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 6 : (D <= 80 ? 3 : 1));
+#elif defined(A2_WPS5)
+  constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 5 : (D <= 80 ? 3 : 1));
+#else
   constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 4 : (D <= 80 ? 3 : 1));
+#endif
   constexpr int DVT = (D + 31) / 32;
   constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128);
   static bool attr_set = false;
