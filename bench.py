@@ -53,14 +53,15 @@ def main():
     rank, world = dp.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     _lib.load()
 
     geom = None if args.small else FULL
     ctx = (5, 64) if args.small else (257, 768)
     t0 = time.time()
-    ref, den, ref_sd, den_sd = build_models(geom=geom, device=dev)
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    ref, den, ref_sd, den_sd = build_models(geom=geom, device=dev, keep_state_dicts=want_cpu)
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     pipe.reference_reuse = not args.no_reuse
     h = w = args.size // 8

@@ -17,9 +17,9 @@ def init(backend=None):
     if world == 1:
         return 0, 1
     if not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        backend = backend or os.environ.get("MD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
@@ -41,11 +41,13 @@ def scatter_clips(clips, device, src=0):
         meta[0] = [(tuple(t.shape), t.dtype) for t in clips[0]]
     dist.broadcast_object_list(meta, src=src)
     out = []
+    # RCCL moves device tensors directly; the gloo backend (CPU tests, single-GPU dry runs) stages through host memory
+    comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     for slot, (shape, dtype) in enumerate(meta[0]):
-        recv = torch.empty(shape, dtype=dtype, device=device)
-        send = [c[slot].to(device).contiguous() for c in clips] if rank == src else None
+        recv = torch.empty(shape, dtype=dtype, device=comm_dev)
+        send = [c[slot].to(comm_dev).contiguous() for c in clips] if rank == src else None
         dist.scatter(recv, send, src=src)
-        out.append(recv)
+        out.append(recv.to(device))
     return tuple(out)
 
 
@@ -54,9 +56,12 @@ def gather_latents(latents, dst=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [latents]
     rank, world = dist.get_rank(), dist.get_world_size()
+    device = latents.device
+    if dist.get_backend() != "nccl":
+        latents = latents.cpu()
     bucket = [torch.empty_like(latents) for _ in range(world)] if rank == dst else None
     dist.gather(latents.contiguous(), bucket, dst=dst)
-    return bucket
+    return [b.to(device) for b in bucket] if bucket is not None else None
 
 
 def barrier():
@@ -67,6 +72,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -18,18 +18,25 @@ SCHED_KWARGS = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", 
                     prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
 
 
-def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device="cuda", dtype=torch.float16):
-    """Both UNets with seeded synthetic weights (no checkpoints exist offline).  Returns (ref, den, ref_sd, den_sd)."""
+def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device="cuda", dtype=torch.float16, keep_state_dicts=True):
+    """Both UNets with seeded synthetic weights (no checkpoints exist offline).  Returns (ref, den, ref_sd, den_sd); the fp32
+    state dicts are dropped (None) unless keep_state_dicts -- they are only needed to feed the CPU oracle.  One model at a
+    time is materialised on the host (8 ranks x 2.2 G fp32 parameters would otherwise cost ~150 GB of host RAM)."""
     from . import UNet2DConditionModel, UNet3DConditionModel
     from .synth import synth_state_dict
     geom = dict(SMALL if geom is None else geom)
-    den = UNet3DConditionModel(sample_size=16, **geom, **MM_KWARGS)
-    ref = UNet2DConditionModel(sample_size=16, **geom)
-    den_sd = synth_state_dict({k: tuple(v.shape) for k, v in den.state_dict().items()}, seed=seed_den, mode=mode)
-    ref_sd = synth_state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, seed=seed_ref, mode=mode)
-    den.load_state_dict(den_sd, strict=True)
-    ref.load_state_dict(ref_sd, strict=True)
-    return ref.to(device=device, dtype=dtype), den.to(device=device, dtype=dtype), ref_sd, den_sd
+    out = []
+    for cls, kw, seed in ((UNet2DConditionModel, {}, seed_ref), (UNet3DConditionModel, MM_KWARGS, seed_den)):
+        with torch.device("meta"):
+            shapes = {k: tuple(v.shape) for k, v in cls(sample_size=16, **geom, **kw).state_dict().items()}
+        sd = synth_state_dict(shapes, seed=seed, mode=mode)
+        model = cls(sample_size=16, **geom, **kw)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(device=device, dtype=dtype)
+        out.append((model, sd if keep_state_dicts else None))
+        del sd
+    (ref, ref_sd), (den, den_sd) = out
+    return ref, den, ref_sd, den_sd
 
 
 def rel_l2(a, b):
