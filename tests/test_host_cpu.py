@@ -72,3 +72,18 @@ def test_scene_motion_matches_reference(golden_dir):
     assert flow.shape == (16, 2, 24, 24) and np.abs(flow - z["flow"]).max() <= 1e-12
     eye = [np.eye(4)] * 5
     assert np.abs(camera_to_scene_motion(eye, eye, list(z["K"]), np.zeros((1, 24, 24)), 24, 24, False)).max() == 0
+
+
+def test_hot_path_refuses_cpu_tensors_and_odd_latents():
+    from mikudance_amd.unet_3d_mix import _UNetBase
+    with torch.device("meta"):
+        den = M.UNet3DConditionModel(sample_size=16, **SMALL, **MM_KWARGS)
+        ref = M.UNet2DConditionModel(sample_size=16, **SMALL)
+    pipe = M.MikuDanceVideoPipeline(None, None, ref, den, M.DDIMScheduler(**SCHED_KWARGS))
+    with pytest.raises(RuntimeError):
+        pipe.denoise(torch.zeros(1, 4, 2, 16, 16), torch.zeros(1, 2, 22, 16, 16), torch.zeros(2, 5, 64), 1, 3.5)
+    with pytest.raises(ValueError):
+        _UNetBase._check_latent_size(12, 16, 4)          # 12 is not a multiple of 8: needs the reference's upsample_size path
+    _UNetBase._check_latent_size(96, 96, 4)
+    with pytest.raises(AssertionError):
+        den.forward(torch.zeros(1, 4, 16, 16), 0, torch.zeros(1, 5, 64))       # 5-D input required (transformer_3d.py:117-119)

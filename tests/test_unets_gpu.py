@@ -133,3 +133,65 @@ def test_config1_full_width_vs_oracle():
         want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 2, guidance_scale=3.5, reduced=True)
     r, c = rel_l2(out.float(), want), cosine(out.float(), want)
     assert r < 3e-2 and c > 0.999, (r, c)
+
+
+class _FakeVAE(torch.nn.Module):
+    """Duck-typed stand-in for diffusers AutoencoderKL (the pipeline only touches encode().latent_dist.mean, decode().sample,
+    .dtype, .device): 8x average pooling to 4 channels and nearest upsampling back."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    dtype = property(lambda self: self.p.dtype)
+    device = property(lambda self: self.p.device)
+
+    def encode(self, x):
+        z = torch.nn.functional.avg_pool2d(x, 8)
+        z = torch.cat([z, z.mean(1, keepdim=True)], 1)
+        return type("E", (), {"latent_dist": type("D", (), {"mean": z})})
+
+    def decode(self, z, **kw):
+        return type("S", (), {"sample": torch.nn.functional.interpolate(z[:, :3], scale_factor=8.0, mode="nearest")})
+
+
+class _FakeCLIP(torch.nn.Module):
+    def __init__(self, tokens=5, dim=64):
+        super().__init__()
+        self.tokens, self.dim = tokens, dim
+        self.vision_model = type("V", (), {"post_layernorm": torch.nn.Identity()})()
+        self.visual_projection = torch.nn.Identity()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    dtype = property(lambda self: self.p.dtype)
+
+    def forward(self, pixel_values):
+        g = torch.Generator().manual_seed(3)
+        h = torch.randn(1, self.tokens, self.dim, generator=g).to(pixel_values.device, pixel_values.dtype)
+        return type("O", (), {"last_hidden_state": h + pixel_values.mean() * 0})
+
+
+def test_pipeline_call_signature_end_to_end(small):
+    """The reference call of scripts/inference_video.py:211-224 (positional order, PIL inputs, CPU generator) through
+    MikuDanceVideoPipeline.__call__ and Pose2VideoPipeline.__call__, with duck-typed VAE / CLIP modules."""
+    from PIL import Image
+    import numpy as np
+    from mikudance_amd import Pose2VideoPipeline
+    meta, ref, den, ref_sd, den_sd, t = small
+    H = W = 128
+    F_ = 3
+    rng = np.random.default_rng(0)
+    img = lambda: Image.fromarray(rng.integers(0, 255, (160, 144, 3), dtype=np.uint8))
+    flow = rng.uniform(-0.03, 0.03, (F_, 2, H // 8, W // 8))
+    for cls in (MikuDanceVideoPipeline, Pose2VideoPipeline):
+        pipe = cls(vae=_FakeVAE(), image_encoder=_FakeCLIP(), reference_unet=ref, denoising_unet=den,
+                   scheduler=DDIMScheduler(**SCHED_KWARGS))
+        pipe = pipe.to("cuda", dtype=torch.float16)
+        gen = torch.manual_seed(42)
+        out = pipe(img(), img(), [img() for _ in range(F_)], [img() for _ in range(F_)], [img() for _ in range(F_)], flow, W, H, F_,
+                   2, 3.5, generator=gen)
+        v = out.videos
+        assert tuple(v.shape) == (1, 3, F_, H, W) and v.dtype == torch.float32 and v.device.type == "cpu"
+        assert torch.isfinite(v).all() and float(v.min()) >= 0.0 and float(v.max()) <= 1.0
+    with pytest.raises(ValueError):
+        pipe.prepare_latents(2, 4, W, H, F_, torch.float16, "cuda", [torch.manual_seed(0)])
