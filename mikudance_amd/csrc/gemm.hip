@@ -28,8 +28,6 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define BN 128
-#define CS_LD 132  // fp32 staging row pitch
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3 };
 
@@ -70,9 +68,12 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-template <bool CONV, int BK, int NSTAGE, int WM, int WPS, bool GEGLU>
+template <bool CONV, int BK, int NSTAGE, int WM, int WPS, bool GEGLU, int NJ>
 __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
   constexpr int BM = WM * 64;
+  constexpr int BN = 64 * NJ;              // 2 waves along N, NJ 32-column MFMA tiles each
+  constexpr int CS_LD = BN + 4;            // fp32 staging row pitch
+  static_assert(!GEGLU || NJ == 2, "GEGLU pairs the two column sub-tiles of a wave");
   constexpr int NW = WM * 2;               // waves
   constexpr int T = NW * 64;               // threads
   (void)T;
@@ -166,11 +167,11 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < IPB; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + k0), (lptr_t)(sw + j * 1024), 16, 0, 0);
   };
 
-  floatx16 acc[2][2];
+  floatx16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -180,14 +181,18 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     if (s < nk) issue_tile(s, s);
 
   const int frow = lane & 31, fhi = lane >> 5;
-  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+  int a_off[2], b_off[NJ], a_sw[2], b_sw[NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+    const int ra = wm * 64 + i * 32 + frow;
     a_off[i] = ra * ROWB;
-    b_off[i] = OPA + rb * ROWB;
     a_sw[i] = (ra >> SW_SHIFT) & SW_MASK;
-    b_sw[i] = (rb >> SW_SHIFT) & SW_MASK;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int rb = wn * (32 * NJ) + j * 32 + frow;
+    b_off[j] = OPA + rb * ROWB;
+    b_sw[j] = (rb >> SW_SHIFT) & SW_MASK;
   }
 
   int stage = 0;
@@ -212,19 +217,18 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     const char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      half8_t af[2], bf[2];
+      half8_t af[2], bf[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
-        bf[i] = *reinterpret_cast<const half8_t*>(sb + b_off[i] + (((s * 2 + fhi) ^ b_sw[i]) << 4));
-      }
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const half8_t*>(sb + b_off[j] + (((s * 2 + fhi) ^ b_sw[j]) << 4));
       // the workgroups sharing this CU sit in different phases (DMA issue / LDS reads / epilogue): favour whoever has
       // its operands ready for the matrix pipe (guide T5)
       if (!CONV) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = GEGLU ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
       if (!CONV) __builtin_amdgcn_s_setprio(0);
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
       for (int g = 0; g < 4; ++g) {
         half4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)((acc[i][0][4 * g + e] + (float)bh[g][e]) * gelu_fast(acc[i][1][4 * g + e] + (float)bg[g][e]));
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)((acc[i][0][4 * g + e] + (float)bh[g][e]) * gelu_fast(acc[i][NJ - 1][4 * g + e] + (float)bg[g][e]));
         *reinterpret_cast<half4_t*>(drow + 8 * g) = o;
       }
     }
@@ -271,7 +275,8 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 
   // ---- epilogue: accumulators -> LDS (fp32, 64 rows per pass) -> coalesced rows
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  constexpr int RP = T / 16;      // rows per sweep of the plain epilogue (16 threads x 8 columns per row)
+  constexpr int TPR = BN / 8;     // threads per row of the plain epilogue (8 columns each)
+  constexpr int RP = T / TPR;     // rows per sweep
   constexpr int NI = 64 / RP;     // sweeps per 64-row pass
 #pragma unroll 1
   for (int pass = 0; pass < WM; ++pass) {
@@ -281,11 +286,11 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     half8_t rv[NI];
     bool rvec[NI];
     {
-      const int n = n0 + (tid & 15) * 8;
+      const int n = n0 + (tid % TPR) * 8;
       const bool nvec = (p.N - n) >= 8;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int m = mp + (tid >> 4) + RP * i;
+        const int m = mp + (tid / TPR) + RP * i;
         rvec[i] = false;
         if (p.residual && m < p.M && nvec) {
           const half_t* rs = p.residual + (size_t)m * p.ldr + n;
@@ -301,11 +306,11 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-            const int col = wn * 64 + j * 32 + frow;
+            const int col = wn * (32 * NJ) + j * 32 + frow;
             Cs[row * CS_LD + col] = acc[i][j][r];
           }
     }
@@ -313,13 +318,13 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 
     if (p.transpose_out) {
       // out[n][m]: thread owns one column n and 8 consecutive rows -> one 16-B store along m
-      const int col = tid & 127;
+      const int col = tid % BN;
       const int n = n0 + col;
       if (n < p.N) {
         const float bv = p.bias ? (float)p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8 / (T / 128); ++i) {
-          const int rc = (tid >> 7) + (T / 128) * i;
+        for (int i = 0; i < 8 / (T / BN); ++i) {
+          const int rc = (tid / BN) + (T / BN) * i;
           const int m = mp + rc * 8;
           if (m >= p.M) continue;
           half8_t o;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
         }
       }
     } else {
-      const int col8 = (tid & 15) * 8;
+      const int col8 = (tid % TPR) * 8;
       const int n = n0 + col8;
       const int nv = (p.N - n) < 8 ? (p.N - n) : 8;   // <= 0: this thread's columns are outside the matrix
       const bool nvec = nv == 8;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int row = (tid >> 4) + RP * i;
+        const int row = (tid / TPR) + RP * i;
         const int m = mp + row;
         if (m >= p.M || nv <= 0) continue;
         float v[8];
@@ -412,25 +417,21 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 //   6: BK=64 x 1 stage  = 34 KiB  -> 3 workgroups/CU (<= 168 registers), load latency covered by the other workgroups
 //      (default for Linear GEMMs: measured best on every config-2 shape, 856 TF at 8192^3)
 //   big: 256x128, BK=64 x 3 stages = 144 KiB, 8 waves, 1 workgroup/CU, two 48-KiB tiles in flight
-static constexpr size_t kCsBytes = (size_t)64 * CS_LD * 4;
-template <int BK, int NSTAGE, int WM>
-static constexpr size_t gemm_smem() {
-  return ((size_t)NSTAGE * (WM * 64 + BN) * BK * 2 > kCsBytes) ? (size_t)NSTAGE * (WM * 64 + BN) * BK * 2 : kCsBytes;
-}
-
-template <bool CONV, bool GEGLU, int BK, int NSTAGE, int WM = 2, int WPS = 1>
+template <bool CONV, bool GEGLU, int NJ, int BK, int NSTAGE, int WM = 2, int WPS = 1>
 static void launch_variant(GemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
+  constexpr int BN = 64 * NJ;
   constexpr size_t ring = (size_t)NSTAGE * (WM * 64 + BN) * BK * 2;
-  constexpr size_t smem = GEGLU ? ring : (ring > kCsBytes ? ring : kCsBytes);
+  constexpr size_t cs = (size_t)64 * (BN + 4) * 4;
+  constexpr size_t smem = GEGLU ? ring : (ring > cs ? ring : cs);
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   p.tiles_n = cdiv(p.N, BN);
   p.tiles_total = cdiv(p.M, WM * 64) * p.tiles_n;
-  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU>), dim3(p.tiles_total), dim3(WM * 128), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ>), dim3(p.tiles_total), dim3(WM * 128), smem, stream, p);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -440,22 +441,34 @@ static int env_int(const char* name, int dflt) {
 
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
-  static int variant = -1, big = -1;
+  static int variant = -1, big = -1, narrow = -1;
   if (variant < 0) {
     variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
     big = env_int("MD_GEMM_BIG", 0);
+    narrow = env_int("MD_GEMM_NARROW", 0);
+  }
+  if constexpr (!GEGLU) {
+    // 64-column tiles: always for N <= 64 (conv_out, N = 4).  For N = 320 (5 x 64 instead of 3 x 128, 17 % fewer MFMAs) the
+    // same-box A/B on MI355X is a wash (the 64x32 wave tile needs 1.5 LDS fragment reads per MFMA instead of 1), so that
+    // case stays opt-in (MD_GEMM_NARROW=1).
+    const int rem = p.N % 128;
+    if (p.N <= 64 || (narrow && rem > 0 && rem <= 64)) {
+      if (CONV) launch_variant<CONV, false, 1, 64, 2>(p, stream);
+      else launch_variant<CONV, false, 1, 64, 1, 2, 3>(p, stream);
+      return;
+    }
   }
   // the 256-row tile needs enough work to fill 256 CUs with ONE workgroup each and a deep K loop to amortise its ring
-  const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
+  const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
   if (big && tiles256 >= 512 && p.K >= 512) {
-    launch_variant<CONV, GEGLU, 64, 3, 4>(p, stream);
+    launch_variant<CONV, GEGLU, 2, 64, 3, 4>(p, stream);
     return;
   }
   switch (variant) {
-    case 0: launch_variant<CONV, GEGLU, 32, 4>(p, stream); break;
-    case 1: launch_variant<CONV, GEGLU, 32, 3>(p, stream); break;
-    case 6: launch_variant<CONV, GEGLU, 64, 1, 2, 3>(p, stream); break;
-    default: launch_variant<CONV, GEGLU, 64, 2>(p, stream); break;
+    case 0: launch_variant<CONV, GEGLU, 2, 32, 4>(p, stream); break;
+    case 1: launch_variant<CONV, GEGLU, 2, 32, 3>(p, stream); break;
+    case 6: launch_variant<CONV, GEGLU, 2, 64, 1, 2, 3>(p, stream); break;
+    default: launch_variant<CONV, GEGLU, 2, 64, 2>(p, stream); break;
   }
 }
 
