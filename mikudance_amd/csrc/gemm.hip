@@ -68,9 +68,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-template <bool CONV, int BK, int NSTAGE, int WM, int WPS, bool GEGLU, int NJ>
+template <bool CONV, int BK, int NSTAGE, int WM, int WPS, bool GEGLU, int NJ, int MI>
 __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
-  constexpr int BM = WM * 64;
+  constexpr int WROWS = 32 * MI;           // rows of the output tile owned by one wave (MI 32-row MFMA tiles)
+  constexpr int BM = WM * WROWS;
   constexpr int BN = 64 * NJ;              // 2 waves along N, NJ 32-column MFMA tiles each
   constexpr int CS_LD = BN + 4;            // fp32 staging row pitch
   static_assert(!GEGLU || NJ == 2, "GEGLU pairs the two column sub-tiles of a wave");
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < IPB; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + k0), (lptr_t)(sw + j * 1024), 16, 0, 0);
   };
 
-  floatx16 acc[2][NJ];
+  floatx16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -181,10 +182,10 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     if (s < nk) issue_tile(s, s);
 
   const int frow = lane & 31, fhi = lane >> 5;
-  int a_off[2], b_off[NJ], a_sw[2], b_sw[NJ];
+  int a_off[MI], b_off[NJ], a_sw[MI], b_sw[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + frow;
+  for (int i = 0; i < MI; ++i) {
+    const int ra = wm * WROWS + i * 32 + frow;
     a_off[i] = ra * ROWB;
     a_sw[i] = (ra >> SW_SHIFT) & SW_MASK;
   }
@@ -217,16 +218,16 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     const char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      half8_t af[2], bf[NJ];
+      half8_t af[MI], bf[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const half8_t*>(sb + b_off[j] + (((s * 2 + fhi) ^ b_sw[j]) << 4));
       // the workgroups sharing this CU sit in different phases (DMA issue / LDS reads / epilogue): favour whoever has
       // its operands ready for the matrix pipe (guide T5)
       if (!CONV) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = GEGLU ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + lc;
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WROWS + i * 32 + lc;
       if (m >= p.M) continue;
       half_t* drow = p.C + (size_t)m * p.ldc + nb + 4 * hi;
 #pragma unroll
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
   constexpr int RP = T / TPR;     // rows per sweep
   constexpr int NI = 64 / RP;     // sweeps per 64-row pass
 #pragma unroll 1
-  for (int pass = 0; pass < WM; ++pass) {
+  for (int pass = 0; pass < BM / 64; ++pass) {
     const int mp = m0 + pass * 64;
     // residual rows of this pass (plain epilogue): issue the loads BEFORE the staging barriers so that their HBM
     // latency overlaps the accumulator -> LDS traffic
@@ -302,16 +303,22 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
       }
     }
     __syncthreads();
-    if (wm == pass) {
+    if (wm == (pass * 64) / WROWS) {
+      // this wave owns the 64 rows of the pass: its m-tiles i0, i0+1
+      const int i0 = ((pass * 64) % WROWS) / 32;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
             const int col = wn * (32 * NJ) + j * 32 + frow;
-            Cs[row * CS_LD + col] = acc[i][j][r];
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+              if (i == i0 + ii) v = acc[i][j][r];     // static register index, uniform select
+            Cs[row * CS_LD + col] = v;
           }
     }
     __syncthreads();
@@ -417,21 +424,21 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 //   6: BK=64 x 1 stage  = 34 KiB  -> 3 workgroups/CU (<= 168 registers), load latency covered by the other workgroups
 //      (default for Linear GEMMs: measured best on every config-2 shape, 856 TF at 8192^3)
 //   big: 256x128, BK=64 x 3 stages = 144 KiB, 8 waves, 1 workgroup/CU, two 48-KiB tiles in flight
-template <bool CONV, bool GEGLU, int NJ, int BK, int NSTAGE, int WM = 2, int WPS = 1>
+template <bool CONV, bool GEGLU, int NJ, int BK, int NSTAGE, int WM = 2, int WPS = 1, int MI = 2>
 static void launch_variant(GemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
   constexpr int BN = 64 * NJ;
-  constexpr size_t ring = (size_t)NSTAGE * (WM * 64 + BN) * BK * 2;
+  constexpr size_t ring = (size_t)NSTAGE * (WM * 32 * MI + BN) * BK * 2;
   constexpr size_t cs = (size_t)64 * (BN + 4) * 4;
   constexpr size_t smem = GEGLU ? ring : (ring > cs ? ring : cs);
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ, MI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   p.tiles_n = cdiv(p.N, BN);
-  p.tiles_total = cdiv(p.M, WM * 64) * p.tiles_n;
-  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ>), dim3(p.tiles_total), dim3(WM * 128), smem, stream, p);
+  p.tiles_total = cdiv(p.M, WM * 32 * MI) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ, MI>), dim3(p.tiles_total), dim3(WM * 128), smem, stream, p);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -444,7 +451,7 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   static int variant = -1, big = -1, narrow = -1;
   if (variant < 0) {
     variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
-    big = env_int("MD_GEMM_BIG", 0);
+    big = env_int("MD_GEMM_BIG", -1);   // -1: automatic
     narrow = env_int("MD_GEMM_NARROW", 0);
   }
   if constexpr (!GEGLU) {
@@ -460,8 +467,20 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   }
   // the 256-row tile needs enough work to fill 256 CUs with ONE workgroup each and a deep K loop to amortise its ring
   const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
-  if (big && tiles256 >= 512 && p.K >= 512) {
-    launch_variant<CONV, GEGLU, 2, 64, 3, 4>(p, stream);
+  if (big == 1 && tiles256 >= 512 && p.K >= 512) {
+    launch_variant<CONV, GEGLU, 2, 64, 3, 4>(p, stream);        // 8 waves, 64x64 per wave, 3-deep ring
+    return;
+  }
+  // 256x128 tile, 4 waves x (128x64 per wave = 4x2 MFMA tiles, 8 independent accumulators), single 48-KiB stage, 2
+  // workgroups/CU: 0.75 LDS fragment reads and 0.75x the DMA bytes per MFMA of the 128x128 tile.  Same-box A/B on MI355X:
+  // +5..11 % on the 3x3 convs with >= 1024 such tiles and on every GEGLU GEMM (935 TF at 8192^3), but slower on the
+  // HBM-bound skinny Linear GEMMs and on the 24x24 / 12x12 convs (too few tiles to fill 256 CUs twice).
+  if (big == 2 || (big < 0 && tiles256 >= 1024 && (CONV || GEGLU))) {
+    launch_variant<CONV, GEGLU, 2, 64, 1, 2, 2, 4>(p, stream);
+    return;
+  }
+  if (big == 3 && tiles256 >= 512) {
+    launch_variant<CONV, GEGLU, 2, 32, 2, 2, 2, 4>(p, stream);  // 4 waves, 128x64 per wave, BK=32 double buffer
     return;
   }
   switch (variant) {
