@@ -164,8 +164,15 @@ class CrossContext:
     frame to its context batch, Lk valid tokens, Lpad stride.  K/V projections of the context are cached per block
     (step-invariant; SURVEY.md 2.2 'cross k/v')."""
 
-    def __init__(self, ctx, index, lk, lpad, key):
+    def __init__(self, ctx, index, lk, lpad, key, zero_frames=0):
         self.ctx, self.index, self.lk, self.lpad, self.key = ctx, index, lk, lpad, key
+        # leading frames whose context is all zeros (the CFG unconditional half: reference
+        # src/pipelines/pipeline_mikudance.py:418-423 builds it with zeros_like).  For those rows K = V = 0 (to_k / to_v
+        # have no bias), so the cross-attention output is exactly the to_out bias: see TransformerBlock.forward.
+        self.zero_frames = zero_frames
+
+
+ZERO_CONTEXT_SKIP = True     # tests switch this off to compare against the literal evaluation
 
 
 class TransformerBlock(_Packed):
@@ -238,17 +245,30 @@ class TransformerBlock(_Packed):
             q, k = qk[:, :C], qk[:, C:]
             vt = ops.gemm(n, pk["v1"], transpose_out=True)
         a = ops.attention(q, k, vt, B, H, D, L, L)
-        h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h)
-        # cross attention to the CLIP tokens
-        n2 = ops.layernorm(h, pk["n2w"], pk["n2b"])
-        q2 = ops.gemm(n2, pk["q2"])
         kv2 = self._kv_cache.get(cross.key)
         if kv2 is None:
             self._kv_cache.clear()
-            kv2 = (ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True))
+            kv2 = (ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True), {})
             self._kv_cache[cross.key] = kv2
-        a2 = ops.attention(q2, kv2[0], kv2[1], B, H, D, L, cross.lk, kv_stride=cross.lpad, kv_index=cross.index)
-        h = ops.gemm(a2, pk["o2"], bias=pk["o2b"], residual=h)
+        zf = min(cross.zero_frames, B) if ZERO_CONTEXT_SKIP else 0
+        if zf:
+            # frames with an all-zero context: cross-attention == to_out bias.  It rides on the attn1 out-projection as a
+            # per-frame row-broadcast term, and those rows skip norm2 / to_q / attention / to_out altogether.
+            tab = kv2[2].get((B, zf))
+            if tab is None:
+                tab = torch.zeros((B, C), device=h.device, dtype=torch.float16)
+                tab[:zf] = pk["o2b"]
+                kv2[2][(B, zf)] = tab
+            h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h, rowadd=tab, rows_per_group=L)
+        else:
+            h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h)
+        # cross attention to the CLIP tokens
+        if zf < B:
+            hs = h[zf * L:]
+            n2 = ops.layernorm(hs, pk["n2w"], pk["n2b"])
+            q2 = ops.gemm(n2, pk["q2"])
+            a2 = ops.attention(q2, kv2[0], kv2[1], B - zf, H, D, L, cross.lk, kv_stride=cross.lpad, kv_index=cross.index[zf:])
+            ops.gemm(a2, pk["o2"], bias=pk["o2b"], residual=hs, out=hs)    # in place: each element is read and written by one thread
         n3 = ops.layernorm(h, pk["n3w"], pk["n3b"])
         return _run_ff(pk, n3, h)
 

@@ -13,6 +13,12 @@
 //  * The O^T rescale is skipped unless some row's running maximum grows by more than 2^5 (wave-uniform test, exact
 //    arithmetic otherwise: P <= 32 in fp16 keeps its relative precision).
 //  * P is packed with v_cvt_pk_f16_f32 (round to nearest).
+//  * Head dims with D % 16 == 8 (8, 40) leave eight unused k-slots in the last Q K^T step.  The matrix core then also does
+//    the "scale, subtract the running reference" of the softmax: Q is pre-multiplied by scale*log2(e), slot D of every Q row
+//    holds -m (the row's running reference, kept fp16-representable so that the product is exact) and slot D of every K row
+//    reads a constant 1.0 from LDS, so S' = log2e*scale*q.k - m comes straight out of the MFMA and the per-score work is
+//    exp2 + pack only (measured on MI355X: this kernel is bound by VALU issue -- 72 % busy vs 47 % for the MFMA pipe --
+//    and the fma was 32 of its ~125 VALU instructions per 64-key tile).  m moves only in the (rare) rescale branch.
 #pragma once
 #include "common.h"
 #include <stdlib.h>
@@ -59,6 +65,12 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   constexpr int STAGE = KBYTES + VBYTES;
   constexpr int NKI = KBYTES / 1024, NVI = (D * 128) / 1024;  // DMA instructions per tile (K, V^T)
   constexpr int NI = NKI + NVI;
+#ifdef A2_NO_FOLD
+  constexpr bool FOLD = false;
+#else
+  constexpr bool FOLD = (D % 16) == 8;         // softmax reference folded into the last k-step (see header)
+#endif
+  constexpr int CONST_OFF = NST * STAGE;       // FOLD: two 16-B blocks {1,0,...,0}, 32 K rows apart (one per 32-key sub-tile)
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,6 +113,12 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     }
   }
 
+  if (FOLD && tid < 2) {
+    half8_t w = {(half_t)1.0f, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<half8_t*>(smem + CONST_OFF + tid * 32 * KROWB) = w;
+  }
+
+  const float sc = p.scale_log2;
   half8_t qf[QT][KS];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
@@ -111,6 +129,10 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
       const int c = s * 16 + hi * 8;
       half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (c < D) v = *reinterpret_cast<const half8_t*>(Qp + c);
+      if (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * sc);
+      }
       qf[u][s] = v;
     }
   }
@@ -176,14 +198,13 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   float m_run[QT], l_run[QT];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
-    m_run[u] = NEG_BIG;
+    m_run[u] = FOLD ? 0.f : NEG_BIG;
     l_run[u] = 0.f;
 #pragma unroll
     for (int t = 0; t < DVT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[u][t][r] = 0.f;
   }
-  const float sc = p.scale_log2;
   const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -218,7 +239,9 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        const half8_t kf = *reinterpret_cast<const half8_t*>(ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2);
+        const char* kp = ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2;
+        if (FOLD && k == KS - 1) kp = hi ? smem + CONST_OFF + sub * 32 * KROWB : kp;   // k-slots D.. of every key: {1,0,..,0}
+        const half8_t kf = *reinterpret_cast<const half8_t*>(kp);
 #ifdef A2_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -248,6 +271,36 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[u][0][r]), s[u][1][r]);
       mloc = a2_xhalf_max(mloc);
+      if constexpr (FOLD) {
+        // s already is log2e*scale*q.k - m_run (m_run: fp16-representable reference sitting in slot D of the Q fragment)
+        const bool first = it == 0;
+        if (first || !__all(mloc <= A2_THR)) {
+          const float want = m_run[u] + (first ? mloc : fmaxf(mloc, 0.f));
+          const float m_new = (float)(half_t)fminf(fmaxf(want, -60000.f), 60000.f);
+          const float d = m_new - m_run[u];
+          m_run[u] = m_new;
+          if (hi) qf[u][KS - 1][0] = (half_t)(-m_new);
+          if (!first) {
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[u][t][r] *= alpha;
+          }
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][sub][r] -= d;
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            pf[u][sub * 2 + (r >> 3)][r & 7] = (half_t)__builtin_amdgcn_exp2f(s[u][sub][r]);
+            pf[u][sub * 2 + (r >> 3)][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(s[u][sub][r + 1]);
+          }
+        continue;
+      }
       const float mt = mloc * sc;
       if (!__all(mt <= m_run[u] + A2_THR)) {
         const float m_new = fmaxf(m_run[u], mt);
@@ -332,7 +385,7 @@ static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
   constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 4 : (D <= 80 ? 3 : 1));
 #endif
   constexpr int DVT = (D + 31) / 32;
-  constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128);
+  constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128) + ((D % 16) == 8 ? 32 * D * 2 + 16 : 0);   // + the FOLD constants
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<D, NST, QT, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -157,8 +157,12 @@ class _UNetBase(_Packed):
             lpad = packing.pad_to(L, 8)
             buf = torch.zeros((nkv, lpad, D), device=dev, dtype=torch.float16)
             buf[:, :L] = ctx.to(device=dev, dtype=torch.float16)
+            zero_ctx = (buf == 0).flatten(1).all(1).tolist()              # one host sync per new context, not per step
+            zero_frames = 0
+            while zero_frames < len(index_list) and zero_ctx[index_list[zero_frames]]:
+                zero_frames += 1
             hit = CrossContext(buf.view(nkv * lpad, D), torch.tensor(index_list, dtype=torch.int32, device=dev), L, lpad,
-                               key=key)
+                               key=key, zero_frames=zero_frames)
             self._cross_cache[key] = hit
         return hit
 

@@ -103,6 +103,30 @@ def test_run_to_run_bitwise_determinism(small):
     assert torch.equal(a, b)
 
 
+def test_zero_context_rows_skip_cross_attention(small):
+    """The unconditional half's context is all zeros (reference pipeline_mikudance.py:418-423): K = V = 0, so cross-attention
+    reduces to the to_out bias.  The shortcut must agree with the literal evaluation and must not trigger on non-zero rows."""
+    from mikudance_amd import blocks
+    meta, ref, den, ref_sd, den_sd, t = small
+    emb = t["in.embeds"].cuda().half()
+    assert float(emb[0].abs().max()) == 0.0 and float(emb[1].abs().max()) > 0.0
+    x = t["in.latents"][:, :, :4].repeat(2, 1, 1, 1, 1).cuda().half()
+    outs = {}
+    for flag in (True, False):
+        blocks.ZERO_CONTEXT_SKIP = flag
+        try:
+            den._cross_cache.clear()
+            outs[flag] = den(x, torch.tensor(601), encoder_hidden_states=emb, return_dict=False)[0].float()
+            assert den._cross(emb, [0] * 4 + [1] * 4, x.device).zero_frames == 4
+            assert den._cross(emb.flip(0), [0] * 4 + [1] * 4, x.device).zero_frames == 0
+        finally:
+            blocks.ZERO_CONTEXT_SKIP = True
+            den._cross_cache.clear()
+    # one fp16 rounding instead of two per block on the unconditional rows; the conditional rows are bit-identical
+    assert rel_l2(outs[True], outs[False]) < 5e-3, rel_l2(outs[True], outs[False])
+    assert torch.equal(outs[True][1], outs[False][1])
+
+
 def test_long_clip_windows_f30_vs_oracle(small):
     """BASELINE config 5 in miniature: F=40 frames -> wrapping windows of 30 frames (60-frame UNet batches, temporal
     attention over 30 frames, overlap averaging through noise_pred / counter)."""
