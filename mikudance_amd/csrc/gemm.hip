@@ -446,13 +446,29 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+#include "gemm_pp.h"
+
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
-  static int variant = -1, big = -1, narrow = -1;
+  static int variant = -1, big = -1, narrow = -1, pp = -1;
   if (variant < 0) {
     variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
     big = env_int("MD_GEMM_BIG", -1);   // -1: automatic
     narrow = env_int("MD_GEMM_NARROW", 0);
+    pp = env_int("MD_GEMM_PP", 2);      // 0: off, 1: every eligible problem, 2: automatic
+  }
+  // ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
+  // loop long enough to amortise its prologue / epilogue, which no other workgroup covers.  Same-box A/B on MI355X:
+  // +25..28 % on the 96x96 convs (950-1000 TF), +16 % on M=294912 N=320 K=1280, +3..6 % on the K >= 640 GEGLU GEMMs and the
+  // 48x48 convs with K >= 5760; slower on the 24x24 / 12x12 levels (288 / 72 tiles) and on K = 320.
+  if (pp > 0 && pp_eligible<CONV, GEGLU>(p)) {
+    const long tiles = (long)cdiv(p.M, 256) * (p.N / (GEGLU ? 256 : 320));
+    const long rounds = (tiles + 255) / 256;
+    const long fill = tiles * 100 / (rounds * 256);               // % of the CU-rounds that carry a tile
+    if (pp == 1 || (fill >= 88 && p.K >= 640) || (fill >= 75 && p.K >= 5760)) {
+      launch_pp<CONV, GEGLU>(p, stream);
+      return;
+    }
   }
   if constexpr (!GEGLU) {
     // 64-column tiles: always for N <= 64 (conv_out, N = 4).  For N = 320 (5 x 64 instead of 3 x 128, 17 % fewer MFMAs) the

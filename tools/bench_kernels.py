@@ -33,7 +33,7 @@ def main(which):
     if "gemm" in which:
         for M, N, K, geglu in [(294912, 320, 320, False), (294912, 2560, 320, True), (73728, 640, 640, False), (73728, 5120, 640, True),
                                (18432, 1280, 1280, False), (18432, 10240, 1280, True), (294912, 320, 1280, False), (294912, 640, 320, False),
-                               (8192, 8192, 8192, False)]:
+                               (8192, 8192, 8192, False), (73728, 640, 2560, False), (18432, 1280, 5120, False), (8192, 10240, 8192, False), (8192, 10240, 8192, True)]:
             a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
             res = rnd(M, N) if not geglu else None
             o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
