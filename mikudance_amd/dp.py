@@ -66,7 +66,10 @@ def gather_latents(latents, dst=0):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])     # the rank's own GPU (set in init), no device guessing
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device):
