@@ -185,6 +185,30 @@ def g4_g5_unets():
     json.dump(meta, open(os.path.join(OUT, "g4_g5_meta.json"), "w"), indent=1)
 
 
+def g8_fullwidth():
+    """FULL-WIDTH SD-1.5 geometry at BASELINE configs[0] shape (32x32 latents, 4 frames, CFG, 257x768 context): ONE
+    UNet-pair evaluation with the reference's literal call pattern (pipeline_mikudance.py:626-660).  Weights and inputs
+    are regenerated from their seeds by the tests, only the prediction is stored."""
+    from src.models.mutual_mix_attention import ReferenceAttentionControl
+    ref, den, ref_sd, den_sd = build_unets(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1,
+                                       fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1,
+                                       fusion_blocks="full")
+    f, h, w = 4, 32, 32
+    latents, ref_latents, embeds = synth_inputs(f, h, w, ctx_len=257, ctx_dim=768, seed=100)
+    with torch.no_grad():
+        x = latents.repeat(2, 1, 1, 1, 1)
+        g = ref_latents.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w)
+        emb_in = embeds.repeat((f, 1, 1))
+        ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)
+        reader.update(writer)
+        pred = den(x, torch.tensor(601), encoder_hidden_states=emb_in[:2], return_dict=False)[0]
+    save_file({"g8.pred": pred.contiguous()}, os.path.join(OUT, "g8_fullwidth_pred.safetensors"))
+    json.dump({"checksum_den": checksum(den_sd), "checksum_ref": checksum(ref_sd), "timestep": 601, "frames": f, "latent": [h, w],
+               "seed_inputs": 100, "seed_den": 1234, "seed_ref": 4321}, open(os.path.join(OUT, "g8_meta.json"), "w"))
+
+
 def g6_keys():
     ref, den, _, _ = build_unets()      # full SD-1.5 geometry (constructor defaults + cross_attention_dim 768)
     json.dump({"denoising_unet": {k: list(v.shape) for k, v in den.state_dict().items()},
@@ -204,12 +228,13 @@ def g7_ddim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8"]
     if "g1" in which: g1_windows()
     if "g2" in which: g2_scene_motion()
     if "g3" in which: g3_blocks()
     if "g45" in which: g4_g5_unets()
     if "g6" in which: g6_keys()
     if "g7" in which: g7_ddim()
+    if "g8" in which: g8_fullwidth()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -8,7 +8,7 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
-from mikudance_amd.synth import synth_state_dict
+from mikudance_amd.synth import synth_inputs, synth_state_dict
 from oracle import cpu_ref as O
 
 
@@ -113,6 +113,34 @@ def test_g5_loop_literal_and_reduced(small):
         assert rel(got[False][ts], gold) < 2e-4, ts
         # result-preserving reductions (ref UNet once per window, consumed frames only) change nothing
         assert rel(got[True][ts], got[False][ts]) < 1e-5, ts
+
+
+def test_g8_full_width_oracle_vs_reference(golden_dir):
+    """The restatement at FULL WIDTH (SD-1.5 geometry, head dims 40/80/160, 257x768 context) against the prediction of
+    the reference's own modules at configs[0] shape (oracle/gen_golden.py g8)."""
+    meta = json.load(open(os.path.join(golden_dir, "g8_meta.json")))
+    # key -> shape of the SD-1.5 geometry (cross_attention_dim 768) from the product classes on the meta device; their key
+    # layout is itself pinned to the reference's by tests/test_host_cpu.py (G6); the checksums pin the weights
+    from mikudance_amd import UNet2DConditionModel, UNet3DConditionModel
+    from mikudance_amd.selftest import MM_KWARGS
+    full = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    with torch.device("meta"):
+        shapes_den = {k: tuple(v.shape) for k, v in UNet3DConditionModel(sample_size=16, **full, **MM_KWARGS).state_dict().items()}
+        shapes_ref = {k: tuple(v.shape) for k, v in UNet2DConditionModel(sample_size=16, **full).state_dict().items()}
+    den_sd = synth_state_dict(shapes_den, seed=meta["seed_den"])
+    ref_sd = synth_state_dict(shapes_ref, seed=meta["seed_ref"])
+    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
+    assert abs(cs(ref_sd) - meta["checksum_ref"]) < 1e-6 * meta["checksum_ref"]
+    gold = load_file(os.path.join(golden_dir, "g8_fullwidth_pred.safetensors"))["g8.pred"]
+    f, (h, w) = meta["frames"], meta["latent"]
+    lat, rl, emb = synth_inputs(f, h, w, ctx_len=257, ctx_dim=768, seed=meta["seed_inputs"])
+    with torch.no_grad():
+        g = rl.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w)
+        banks, _ = O.reference_unet_forward(ref_sd, g, emb.repeat((f, 1, 1)))
+        banks = {k: v.half().float() for k, v in banks.items()}                    # the reference's fp16 bank cast
+        pred = O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(meta["timestep"]), emb, banks, cfg=True)
+    assert rel(pred, gold) < 1e-4
 
 
 def test_g7_ddim(golden_dir):

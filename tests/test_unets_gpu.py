@@ -159,6 +159,34 @@ def test_config1_full_width_vs_oracle():
     assert r < 3e-2 and c > 0.999, (r, c)
 
 
+def test_g8_full_width_unets_vs_reference_golden(golden_dir):
+    """FULL-WIDTH UNets at configs[0] shape against the prediction of the reference's own modules
+    (tests/golden/g8_fullwidth_pred.safetensors <- oracle/gen_golden.py g8): literal call pattern through the
+    API-compatible forward()s, weights / inputs regenerated from their seeds (checksums pinned in g8_meta.json)."""
+    from mikudance_amd.synth import synth_inputs
+    meta = json.load(open(os.path.join(golden_dir, "g8_meta.json")))
+    gold = load_file(os.path.join(golden_dir, "g8_fullwidth_pred.safetensors"))["g8.pred"]
+    full = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    ref, den, ref_sd, den_sd = build_models(geom=full, seed_den=meta["seed_den"], seed_ref=meta["seed_ref"])
+    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
+    assert abs(cs(ref_sd) - meta["checksum_ref"]) < 1e-6 * meta["checksum_ref"]
+    del ref_sd, den_sd
+    f, (h, w) = meta["frames"], meta["latent"]
+    lat, rl, emb = synth_inputs(f, h, w, ctx_len=257, ctx_dim=768, seed=meta["seed_inputs"])
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
+    g = rl.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w).cuda().half()
+    emb_in = emb.repeat((f, 1, 1)).cuda().half()
+    ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)
+    reader.update(writer)
+    pred = den(lat.repeat(2, 1, 1, 1, 1).cuda().half(), torch.tensor(meta["timestep"]), encoder_hidden_states=emb_in[:2],
+               return_dict=False)[0]
+    reader.clear(); writer.clear()
+    r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
+    assert r < 3e-2 and c > 0.999, (r, c)
+
+
 class _FakeVAE(torch.nn.Module):
     """Duck-typed stand-in for diffusers AutoencoderKL (the pipeline only touches encode().latent_dist.mean, decode().sample,
     .dtype, .device): 8x average pooling to 4 channels and nearest upsampling back."""
