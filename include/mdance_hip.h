@@ -45,6 +45,18 @@ int md_conv3x3_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, i
                         int stride, int upsample, const void* bias, const void* residual, int ldr,
                         const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
 
+/* Same, with pad_lo = 0: the zero padding is (0,1,0,1) (right / bottom only) and stride 2, i.e. F.pad(x, (0,1,0,1)) +
+ * Conv2d(3x3, stride 2, padding 0): the downsampler of the third-party AutoencoderKL encoder (diffusers 0.24.0
+ * Downsample2D(padding=0)) that src/pipelines/pipeline_mikudance.py:456-549 calls through self.vae.encode. */
+int md_conv3x3_pad_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout,
+                            int stride, int upsample, int pad_lo, const void* bias, const void* residual, int ldr,
+                            const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
+
+/* In-place softmax(scale * x) over the rows of a row-major fp16 matrix [rows][ldx] (cols valid, cols % 8 == 0).
+ * The score matrix of the single 512-channel head of the AutoencoderKL mid-block attention (QK^T and PV run on
+ * md_gemm_f16): src/pipelines/pipeline_mikudance.py:115-130 (decode_latents), :456-549 (vae.encode). */
+int md_softmax_rows_f16(void* x, int ldx, int rows, int cols, float scale, void* stream);
+
 /* GroupNorm(G, eps) [+SiLU] over (B, HW, C) NHWC.  src/models/resnet.py:20-28,220-221,231,237;
  * src/models/transformer_3d.py:60-62,130; src/models/motion_module.py:121-123,164; unet_3d_mix.py:591-592. */
 size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G);

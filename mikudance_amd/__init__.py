@@ -2,7 +2,8 @@
 
 Public surface (mirrors the reference's Python API for the hot path):
     UNet3DConditionModel, UNet2DConditionModel (+ UNet2DConditionModelPlain donor), ReferenceAttentionControl,
-    DDIMScheduler, MikuDanceVideoPipeline, Pose2VideoPipeline, get_context_scheduler, camera_to_scene_motion
+    DDIMScheduler, MikuDanceVideoPipeline, Pose2VideoPipeline, get_context_scheduler, camera_to_scene_motion,
+    AutoencoderKL (the next row after the loop: VAE encode / decode on the same kernels)
 All compute goes through libmdance_hip.so (include/mdance_hip.h); importing the package needs neither a GPU nor the
 library, calling any op does.
 """
@@ -13,5 +14,6 @@ from .pipeline_stage2_vdo import Pose2VideoPipeline  # noqa: F401
 from .scheduler import DDIMScheduler  # noqa: F401
 from .unet_2d_mix import UNet2DConditionModel, UNet2DConditionModelPlain  # noqa: F401
 from .unet_3d_mix import UNet3DConditionModel  # noqa: F401
+from .vae import AutoencoderKL  # noqa: F401
 
 __version__ = "0.1.0"

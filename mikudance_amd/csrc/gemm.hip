@@ -44,7 +44,7 @@ struct GemmParams {
   int act;
   int transpose_out;
   // conv
-  int Hin, Win, Cin, Hout, Wout, stride, upsample;
+  int Hin, Win, Cin, Hout, Wout, stride, upsample, pad;   // pad: zero rows/cols before the image (1, or 0 for the VAE downsampler)
   int tiles_n, tiles_total;
 };
 
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
       const int hw = p.Hout * p.Wout;
       const int b = mm / hw, rem = mm - b * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      a_oy[j] = oy * p.stride - 1;          // input row of filter tap ky = 0 (in the possibly upsampled image)
-      a_ox[j] = ox * p.stride - 1;
+      a_oy[j] = oy * p.stride - p.pad;      // input row of filter tap ky = 0 (in the possibly upsampled image)
+      a_ox[j] = ox * p.stride - p.pad;
       a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
     } else {
       a_oy[j] = a_ox[j] = 0;
@@ -537,21 +537,35 @@ extern "C" int md_gemm_f16(const void* A, int lda, const void* W, void* C, int l
   return launch_gemm(p, false, (hipStream_t)stream);
 }
 
-extern "C" int md_conv3x3_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int stride,
-                                   int upsample, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
-                                   int rows_per_group, int act, void* stream) {
+static int conv3x3_common(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int stride,
+                          int upsample, int pad_lo, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
+                          int rows_per_group, int act, void* stream) {
   MD_CHECK_ARG(Cin % 64 == 0, "md_conv3x3: Cin=%d must be a multiple of 64 (zero-pad channels when packing)", Cin);
   MD_CHECK_ARG(stride == 1 || stride == 2, "md_conv3x3: stride must be 1 or 2");
   MD_CHECK_ARG(upsample == 0 || (upsample == 1 && stride == 1), "md_conv3x3: upsample is 0 or 1 (nearest 2x) with stride 1");
+  MD_CHECK_ARG(pad_lo == 1 || (pad_lo == 0 && stride == 2 && upsample == 0), "md_conv3x3: pad_lo is 1, or 0 with stride 2 (pad (0,1,0,1))");
   GemmParams p = {};
   p.A = (const half_t*)X; p.W = (const half_t*)W; p.C = (half_t*)Y;
   p.bias = (const half_t*)bias; p.residual = (const half_t*)residual; p.rowadd = (const half_t*)rowadd;
   p.ldc = ldy; p.ldr = ldr; p.ldra = ldra; p.lda = Cin;
-  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample; p.pad = pad_lo;
   const int hup = Hin << upsample, wup = Win << upsample;
-  p.Hout = (hup + 2 - 3) / stride + 1;
-  p.Wout = (wup + 2 - 3) / stride + 1;
+  p.Hout = (hup + pad_lo + 1 - 3) / stride + 1;
+  p.Wout = (wup + pad_lo + 1 - 3) / stride + 1;
+  MD_CHECK_ARG(p.Hout > 0 && p.Wout > 0, "md_conv3x3: empty output %dx%d", p.Hout, p.Wout);
   p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
   p.rows_per_group = rows_per_group; p.act = act; p.transpose_out = 0;
   return launch_gemm(p, true, (hipStream_t)stream);
+}
+
+extern "C" int md_conv3x3_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int stride,
+                                   int upsample, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
+                                   int rows_per_group, int act, void* stream) {
+  return conv3x3_common(X, W, Y, ldy, B, Hin, Win, Cin, Cout, stride, upsample, 1, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
+}
+
+extern "C" int md_conv3x3_pad_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout,
+                                       int stride, int upsample, int pad_lo, const void* bias, const void* residual, int ldr,
+                                       const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
+  return conv3x3_common(X, W, Y, ldy, B, Hin, Win, Cin, Cout, stride, upsample, pad_lo, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
 }

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       const int hw = p.Hout * p.Wout;
       const int b = mm / hw, rem = mm - b * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      a_oy[j] = oy * p.stride - 1;
-      a_ox[j] = ox * p.stride - 1;
+      a_oy[j] = oy * p.stride - p.pad;
+      a_ox[j] = ox * p.stride - p.pad;
       a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
     } else {
       a_oy[j] = a_ox[j] = 0;

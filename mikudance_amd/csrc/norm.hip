@@ -303,3 +303,51 @@ extern "C" int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void
   MD_CHECK_LAUNCH("md_instnorm_spade");
   return MD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ row softmax
+// In-place softmax(scale * x) over the rows of a row-major fp16 matrix: the score matrix of the VAE mid-block attention
+// (ONE head of 512 channels: too wide for the flash kernel's register tile, so that attention runs as QK^T GEMM ->
+// this kernel -> PV GEMM).  One workgroup per row; the row (<= 32 KiB) stays in L2 between the three sweeps; statistics
+// in fp32.  HBM-bound: 4 bytes per element (read + write once).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* x, long ldx, int cols, float scale_log2) {
+  half_t* row = x + (size_t)blockIdx.x * ldx;
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = cols >> 3;                         // cols % 8 == 0 and 16-B aligned rows (checked by the launcher)
+  float m = -1.0e30f;
+  for (int i = tid; i < nvec; i += 256) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(row + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, (float)v[j]);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < nvec; i += 256) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(row + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f((float)v[j] * scale_log2 - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = tid; i < nvec; i += 256) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(row + i * 8);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(__builtin_amdgcn_exp2f((float)v[j] * scale_log2 - m) * inv);
+    *reinterpret_cast<half8_t*>(row + i * 8) = o;
+  }
+}
+
+extern "C" int md_softmax_rows_f16(void* x, int ldx, int rows, int cols, float scale, void* stream) {
+  MD_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldx >= cols, "md_softmax_rows: rows=%d cols=%d ldx=%d (cols, ldx multiples of 8)", rows, cols, ldx);
+  MD_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "md_softmax_rows: x must be 16-byte aligned");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, (long)ldx, cols, scale * 1.4426950408889634f);
+  MD_CHECK_LAUNCH("md_softmax_rows");
+  return MD_OK;
+}

@@ -58,25 +58,29 @@ def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_
 
 
 def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, stride=1, upsample=False,
-            out=None):
-    """x: (B, H, W, Cin) NHWC contiguous; w: [Cout, 9*Cin] packed (ky, kx, cin); returns (B, Ho, Wo, Cout)."""
+            out=None, pad_lo=1):
+    """x: (B, H, W, Cin) NHWC contiguous; w: [Cout, 9*Cin] packed (ky, kx, cin); returns (B, Ho, Wo, Cout).
+    pad_lo=0 (stride 2 only): zero padding (0,1,0,1) instead of 1 all round (the AutoencoderKL downsampler).
+    `out` may be a channel slice of a wider NHWC tensor (row pitch = its last-dim stride)."""
     _chk(x, "x")
     _chk(w, "w")
     assert x.dim() == 4 and x.is_contiguous()
     B, H, W, Cin = x.shape
     assert w.shape == (cout, 9 * Cin) and w.is_contiguous(), (w.shape, cout, Cin)
     hup, wup = (H * 2, W * 2) if upsample else (H, W)
-    Ho, Wo = (hup - 1) // stride + 1, (wup - 1) // stride + 1
+    Ho, Wo = (hup + pad_lo - 2) // stride + 1, (wup + pad_lo - 2) // stride + 1
     if out is None:
         out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=F16)
-    o2 = out.view(-1, out.shape[-1])
-    ldy = _rowmajor(o2, "out")
+    assert tuple(out.shape) == (B, Ho, Wo, cout) and out.stride(3) == 1 and out.stride(1) == Wo * out.stride(2) \
+        and out.stride(0) == Ho * out.stride(1), "out must be (B, Ho, Wo, cout) with a uniform pixel pitch"
+    ldy = out.stride(2)
     r2 = residual.view(-1, residual.shape[-1]) if residual is not None else None
     ldr = _rowmajor(r2, "residual") if r2 is not None else 0
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
     _chk(bias, "bias")
-    _lib.call("md_conv3x3_nhwc_f16", x.data_ptr(), w.data_ptr(), out.data_ptr(), ldy, B, H, W, Cin, cout, stride,
-              int(upsample), _p(bias), _p(r2), ldr, _p(rowadd), ldra, rows_per_group, act, _st(),
+    _chk(out, "out")
+    _lib.call("md_conv3x3_pad_nhwc_f16", x.data_ptr(), w.data_ptr(), out.data_ptr(), ldy, B, H, W, Cin, cout, stride,
+              int(upsample), int(pad_lo), _p(bias), _p(r2), ldr, _p(rowadd), ldra, rows_per_group, act, _st(),
               meta=(f"conv3x3 B={B} {H}x{W} Cin={Cin} Cout={cout} s={stride} up={int(upsample)}",
                     2.0 * B * Ho * Wo * cout * 9 * Cin, 2.0 * (B * H * W * Cin + cout * 9 * Cin + B * Ho * Wo * cout)))
     return out
@@ -142,6 +146,15 @@ def attention(q, k, vt, B, H, D, Lq, Lk, kv_stride=None, kv_index=None, scale=No
               float(scale if scale is not None else D ** -0.5), _st(),
               meta=(f"attention B={B} H={H} D={D} Lq={Lq} Lk={Lk}", 4.0 * B * H * Lq * Lk * D, 2.0 * B * H * D * (2 * Lq + 2 * Lk)))
     return out
+
+
+def softmax_rows_(x, scale=1.0):
+    """In-place softmax(scale * x) over the rows of a 2-D row-major fp16 matrix."""
+    ld = _rowmajor(x, "x")
+    rows, cols = x.shape
+    _lib.call("md_softmax_rows_f16", x.data_ptr(), ld, rows, cols, float(scale), _st(),
+              meta=(f"softmax_rows {rows}x{cols}", 0.0, 4.0 * rows * cols))
+    return x
 
 
 def temporal_attention(q, k, v, NB, F, HW, H, D, out=None):
