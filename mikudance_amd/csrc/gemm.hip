@@ -491,7 +491,8 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // workgroups/CU: 0.75 LDS fragment reads and 0.75x the DMA bytes per MFMA of the 128x128 tile.  Same-box A/B on MI355X:
   // +5..11 % on the 3x3 convs with >= 1024 such tiles and on every GEGLU GEMM (935 TF at 8192^3), but slower on the
   // HBM-bound skinny Linear GEMMs and on the 24x24 / 12x12 convs (too few tiles to fill 256 CUs twice).
-  if (big == 2 || (big < 0 && tiles256 >= 1024 && (CONV || GEGLU))) {
+  // (plain Linear GEMMs: only with a deep K loop -- +6 % on M=73728 N=640 K=2560, +12 % at 8192^3)
+  if (big == 2 || (big < 0 && tiles256 >= 1024 && (CONV || GEGLU || p.K >= 2048))) {
     launch_variant<CONV, GEGLU, 2, 64, 1, 2, 2, 4>(p, stream);
     return;
   }
