@@ -39,6 +39,18 @@ def main(which):
             o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
             ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=res, act=ops.ACT_GEGLU if geglu else 0, out=o))
             out[f"gemm {M}x{N}x{K}{' geglu' if geglu else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9)
+    if "small" in which:       # the 12x12 level (M = 4608): fewer workgroups than CU slots
+        for M, N, K, geglu in [(4608, 1280, 1280, False), (4608, 10240, 1280, True), (4608, 1280, 5120, False), (4608, 2560, 1280, False)]:
+            a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+            res = rnd(M, N) if not geglu else None
+            o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=res, act=ops.ACT_GEGLU if geglu else 0, out=o))
+            out[f"gemm {M}x{N}x{K}{' geglu' if geglu else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9)
+        for B, H, Cin, Cout in [(32, 12, 1280, 1280), (32, 12, 2560, 1280)]:
+            x, w, b = rnd(B, H, H, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5), rnd(Cout)
+            o = torch.empty((B, H, H, Cout), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.conv3x3(x, w, Cout, bias=b, out=o))
+            out[f"conv {B}x{H}x{H} {Cin}->{Cout}"] = (ms, 2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9)
     if "conv" in which:
         for B, H, Cin, Cout in [(32, 96, 320, 320), (32, 48, 640, 640), (32, 24, 1280, 1280), (32, 24, 2560, 1280), (32, 96, 640, 320),
                                 (32, 48, 1280, 640)]:
