@@ -66,7 +66,7 @@ def main(which):
             ms = timeit(lambda: ops.attention(q, k, vt, B, 8, D, L, L, out=o))
             out[f"attn B={B} L={L} D={D}"] = (ms, 4.0 * B * 8 * L * L * D / ms / 1e9)
     if "temporal" in which:
-        for HW, D in [(9216, 40), (2304, 80), (576, 160)]:
+        for HW, D in [(9216, 40), (2304, 80), (576, 160), (144, 160)]:
             C, F_ = 8 * D, 16
             q, k, v = rnd(2 * F_ * HW, C), rnd(2 * F_ * HW, C), rnd(2 * F_ * HW, C)
             o = torch.empty_like(q)
