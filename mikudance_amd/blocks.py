@@ -353,10 +353,15 @@ class MotionModule(_Packed):
                   fnw=V(tb.ff_norm.weight, dev), fnb=V(tb.ff_norm.bias, dev))
         for i, (ab, nm) in enumerate(zip(tb.attention_blocks, tb.norms)):
             pk[f"n{i}w"], pk[f"n{i}b"] = V(nm.weight, dev), V(nm.bias, dev)
-            pk[f"q{i}"] = L(ab.to_q.weight, dev)
-            pk[f"kv{i}"] = torch.cat([L(ab.to_k.weight, dev), L(ab.to_v.weight, dev)], 0).contiguous()
+            # q = to_q(n + pe[frame]) (PE on the query input only, motion_module.py:416-417) = to_q(n) + pe[frame] @ Wq^T: the
+            # second term is a per-frame constant row, so q, k and v come from ONE GEMM over n (N = 3C) whose epilogue adds
+            # the [pe @ Wq^T | 0 | 0] row of the token's frame (row-broadcast term, as for the time embedding)
+            pk[f"qkv{i}"] = torch.cat([L(ab.to_q.weight, dev), L(ab.to_k.weight, dev), L(ab.to_v.weight, dev)], 0).contiguous()
             pk[f"o{i}"], pk[f"o{i}b"] = L(ab.to_out[0].weight, dev), V(ab.to_out[0].bias, dev)
-            pk[f"pe{i}"] = V(ab.pos_encoder.pe[0], dev)
+            pe = ab.pos_encoder.pe[0].detach().to(dev, torch.float32)
+            tab = torch.zeros((pe.shape[0], 3 * self.dim), device=dev, dtype=torch.float32)
+            tab[:, :self.dim] = pe @ ab.to_q.weight.detach().to(dev, torch.float32).t()
+            pk[f"peq{i}"] = tab.to(torch.float16)
         _pack_ff(tb.ff, dev, pk)
         return pk
 
@@ -370,10 +375,12 @@ class MotionModule(_Packed):
         h = ops.groupnorm(x, pk["nw"], pk["nb"], GROUPS, 1e-6)
         h = ops.gemm(tokens(h), pk["pi"], bias=pk["pib"])
         for i in range(2):
-            n, npe = ops.layernorm(h, pk[f"n{i}w"], pk[f"n{i}b"], add=pk[f"pe{i}"], add_mode=2, rows_per_frame=HW, frames=f)
-            q = ops.gemm(npe, pk[f"q{i}"])
-            kv = ops.gemm(n, pk[f"kv{i}"])
-            a = ops.temporal_attention(q, kv[:, :C], kv[:, C:], nb, f, HW, H, C // H)
+            n = ops.layernorm(h, pk[f"n{i}w"], pk[f"n{i}b"])
+            tab = pk.get(("peq", i, nb, f))
+            if tab is None:
+                tab = pk[("peq", i, nb, f)] = pk[f"peq{i}"][:f].repeat(nb, 1).contiguous()       # one row per (clip-half, frame)
+            qkv = ops.gemm(n, pk[f"qkv{i}"], rowadd=tab, rows_per_group=HW)
+            a = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, f, HW, H, C // H)
             h = ops.gemm(a, pk[f"o{i}"], bias=pk[f"o{i}b"], residual=h)
         n = ops.layernorm(h, pk["fnw"], pk["fnb"])
         h = _run_ff(pk, n, h)
