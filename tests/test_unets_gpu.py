@@ -86,6 +86,21 @@ def test_loop_no_cfg_and_single_window_vs_oracle(small):
     assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
 
 
+def test_non_square_latents_and_odd_frame_count_vs_oracle(small):
+    """512x768-style clips: non-square latents (16 x 24) and an odd frame count (5) through the whole loop."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    from mikudance_amd.synth import synth_inputs
+    lat, rl, emb = synth_inputs(5, 16, 24, ctx_len=5, ctx_dim=64, seed=11)
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 2, guidance_scale=3.5, reduced=True)
+    out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5)
+    assert out.shape == lat.shape
+    assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+    with pytest.raises(ValueError):            # latent sizes must be multiples of 8 (three stride-2 levels + skip concats)
+        pipe.denoise(lat[..., :20].cuda().half(), rl[..., :20].cuda().half(), emb.cuda().half(), 1, 3.5)
+
+
 def test_scheduler_step_api(small):
     sch = DDIMScheduler(**SCHED_KWARGS)
     sch.set_timesteps(20)
