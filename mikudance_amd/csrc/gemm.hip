@@ -68,6 +68,38 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// GEGLU epilogue of one 32x32 h|g accumulator pair, straight from the accumulators.  With acc = mfma(W frag, A frag) lane
+// (m = lane % 32, hi = lane / 32) holds, for its output row m, the columns 8g + 4*hi + {0..3}, g = 0..3: four 8-byte pieces.
+// v_permlane32_swap exchanges pieces between the two lane halves so that the low lane owns columns [16p, 16p+8) and the high
+// lane [16p+8, 16p+16), p = 0, 1: TWO 16-byte stores per lane instead of four 8-byte ones (a row-per-lane epilogue is
+// store-issue bound, not bandwidth bound: guide T21).  `drow` points at column 0 of the 32-column output group in row m.
+__device__ __forceinline__ void geglu_store32(const floatx16& ah, const floatx16& ag, const half4_t (&bh)[4], const half4_t (&bg)[4],
+                                              half_t* drow, int hi, bool row_ok) {
+  unsigned w[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    half4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (half_t)((ah[4 * g + e] + (float)bh[g][e]) * gelu_fast(ag[4 * g + e] + (float)bg[g][e]));
+    __builtin_memcpy(w[g], &o, 8);
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    // pieces g = 2pr (X0) and g = 2pr+1 (X1): afterwards d[.][0] = [X0.low | X1.low], d[.][1] = [X0.high | X1.high] per lane half
+    unsigned lo[2], hi2[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const auto r = __builtin_amdgcn_permlane32_swap(w[2 * pr][d], w[2 * pr + 1][d], false, false);
+      lo[d] = r[0];       // low lanes: own piece 2pr (cols +0..3)      high lanes: low lane's piece 2pr+1 (cols +8..11)
+      hi2[d] = r[1];      // low lanes: high lane's piece 2pr (cols +4..7)  high lanes: own piece 2pr+1 (cols +12..15)
+    }
+    if (row_ok) {
+      const uint4 v = {lo[0], lo[1], hi2[0], hi2[1]};
+      *reinterpret_cast<uint4*>(drow + 16 * pr + 8 * hi) = v;
+    }
+  }
+}
+
 template <bool CONV, int BK, int NSTAGE, int WM, int WPS, bool GEGLU, int NJ, int MI>
 __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
   constexpr int WROWS = 32 * MI;           // rows of the output tile owned by one wave (MI 32-row MFMA tiles)
@@ -259,15 +291,8 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WROWS + i * 32 + lc;
-      if (m >= p.M) continue;
-      half_t* drow = p.C + (size_t)m * p.ldc + nb + 4 * hi;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        half4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)((acc[i][0][4 * g + e] + (float)bh[g][e]) * gelu_fast(acc[i][NJ - 1][4 * g + e] + (float)bg[g][e]));
-        *reinterpret_cast<half4_t*>(drow + 8 * g) = o;
-      }
+      const int mc = m < p.M ? m : p.M - 1;
+      geglu_store32(acc[i][0], acc[i][NJ - 1], bh, bg, p.C + (size_t)mc * p.ldc + nb, hi, m < p.M);
     }
     (void)Nout;
     return;
@@ -465,6 +490,15 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
     const long tiles = (long)cdiv(p.M, 256) * (p.N / (GEGLU ? 256 : 320));
     const long rounds = (tiles + 255) / 256;
     const long fill = tiles * 100 / (rounds * 256);               // % of the CU-rounds that carry a tile
+    if constexpr (GEGLU) {
+      // persistent flavour (gemm_ppg_kernel): the DMA ring runs across output tiles, so short K loops pay no prologue
+      static int persist = -1;
+      if (persist < 0) persist = env_int("MD_GEMM_PP_PERSIST", 1);
+      if (persist && (pp == 1 || (tiles >= 256 && p.K >= (persist == 2 ? 256 : 640)))) {
+        launch_ppg(p, stream);
+        return;
+      }
+    }
     if (pp == 1 || (fill >= 88 && p.K >= 640) || (fill >= 75 && p.K >= 5760)) {
       launch_pp<CONV, GEGLU>(p, stream);
       return;
@@ -514,7 +548,8 @@ static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
   MD_CHECK_ARG((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0, "md_gemm: A/W must be 16-byte aligned");
   MD_CHECK_ARG(conv || p.lda % 8 == 0, "md_gemm: lda=%d must be a multiple of 8", p.lda);
   if (p.act == ACT_GEGLU) {
-    MD_CHECK_ARG(p.N % 64 == 0 && !p.transpose_out && !p.residual && !p.rowadd && p.ldc % 8 == 0, "md_gemm: GEGLU needs N %% 64 == 0 (N=%d), ldc %% 8 == 0 and no residual/rowadd/transpose", p.N);
+    MD_CHECK_ARG(p.N % 64 == 0 && !p.transpose_out && !p.residual && !p.rowadd && p.ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0,
+                 "md_gemm: GEGLU needs N %% 64 == 0 (N=%d), ldc %% 8 == 0, a 16-byte aligned output and no residual/rowadd/transpose", p.N);
   }
   if (p.transpose_out) MD_CHECK_ARG(!p.residual && !p.rowadd && p.act == ACT_NONE, "md_gemm: transposed store supports bias only");
   if (p.rowadd) MD_CHECK_ARG(p.rows_per_group > 0, "md_gemm: rows_per_group must be > 0 with rowadd");

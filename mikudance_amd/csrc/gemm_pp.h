@@ -291,16 +291,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * 64 + i * 32 + lc;
-        if (m >= p.M) continue;
-        half_t* drow = p.C + (size_t)m * p.ldc + (nc >> 1) + 4 * hi;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          half4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o[e] = (half_t)((acc[i][2 * q][4 * g + e] + (float)bh[g][e]) * gelu_fast(acc[i][2 * q + 1][4 * g + e] + (float)bg[g][e]));
-          *reinterpret_cast<half4_t*>(drow + 8 * g) = o;
-        }
+        const int mc = m < p.M ? m : p.M - 1;
+        geglu_store32(acc[i][2 * q], acc[i][2 * q + 1], bh, bg, p.C + (size_t)mc * p.ldc + (nc >> 1), hi, m < p.M);
       }
     }
     return;
@@ -412,4 +404,223 @@ static void launch_pp(GemmParams& p, hipStream_t stream) {
   if (pm < 0) pm = env_int("MD_GEMM_PP_PM", 1);
   if (pm == 0) launch_pp_g<CONV, GEGLU, 0>(p, stream);
   else launch_pp_g<CONV, GEGLU, 1>(p, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ persistent GEGLU flavour
+// gemm_ppg_kernel: the ping-pong structure above for the GEGLU GEMMs (256x256 tiles, plain A addressing), with ONE workgroup
+// per CU that walks over its tiles and keeps the DMA ring running ACROSS tile boundaries: the first three K tiles of the next
+// output tile are issued during the last three fragment-load slots of the current one, so the prologue latency (no other
+// workgroup covers it here) disappears, and the GEGLU epilogues of the two wave groups -- straight from the accumulators,
+// no LDS -- run concurrently in one slot while those DMAs are in flight.  K tiles are numbered g = 0 .. T-1 over all tiles
+// of the workgroup; ring slot g & 3; barrier / vmcnt bookkeeping exactly as in gemm_pp_kernel with T in place of nk.
+__global__ __launch_bounds__(512, 2) void gemm_ppg_kernel(GemmParams p) {
+  constexpr int BK = 32, MI = 2, NJ = 4;
+  constexpr int BM = 256, BN = 256, NW = 8;
+  constexpr int ROWB = 64, RPI = 16;
+  constexpr int IPA = 2, IPB = 2, G = IPA + IPB;
+  constexpr int OPA = BM * ROWB, STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;
+  const int lrow = lane >> 2, pslot = lane & 3;
+  const int nk = p.K / BK;
+  const int nwg = p.tiles_total;
+  const int ntile = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles of this workgroup
+  const int T = ntile * nk;
+
+  auto tile_origin = [&](int i, int& m0, int& n0) {
+    // virtual workgroup id -> tile, same XCD-aware order as gemm_pp_kernel (gridDim.x % 8 == 0 or gridDim.x == nwg)
+    const int v = (int)blockIdx.x + i * (int)gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    m0 = (t / p.tiles_n) * BM;
+    n0 = (t % p.tiles_n) * BN;
+  };
+
+  // ---- issue side: tile `it`, K tile `ikt` of it, global K-tile counter gi
+  const half_t* a_src[IPA];
+  const half_t* w_src[IPB];
+  auto set_sources = [&](int i) {
+    int m0, n0;
+    tile_origin(i, m0, n0);
+#pragma unroll
+    for (int j = 0; j < IPA; ++j) {
+      const int row = (wave * IPA + j) * RPI + lrow;
+      const int m = m0 + row;
+      a_src[j] = p.A + (size_t)(m < p.M ? m : p.M - 1) * p.lda + (pslot ^ ((row >> 2) & 3)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < IPB; ++j) {
+      const int row = (wave * IPB + j) * RPI + lrow;
+      w_src[j] = p.W + (size_t)(n0 + row) * p.K + (pslot ^ ((row >> 2) & 3)) * 8;
+    }
+  };
+  int it = 0, ikt = 0, gi = 0;
+  set_sources(0);
+  auto issue_next = [&]() {
+    char* sa = smem + (gi & 3) * STAGE + (wave * IPA) * 1024;
+    char* sw = smem + (gi & 3) * STAGE + OPA + (wave * IPB) * 1024;
+    const int k0 = ikt * BK;
+#pragma unroll
+    for (int j = 0; j < IPA; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + k0), (lptr_t)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IPB; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + k0), (lptr_t)(sw + j * 1024), 16, 0, 0);
+    ++gi;
+    if (++ikt == nk) {
+      ikt = 0;
+      if (++it < ntile) set_sources(it);
+    }
+  };
+
+  floatx16 acc[MI][NJ];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[MI], b_off[NJ], a_sw[MI], b_sw[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int ra = wm * 64 + i * 32 + frow;
+    a_off[i] = ra * ROWB;
+    a_sw[i] = (ra >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int rb = wn * (32 * NJ) + j * 32 + frow;
+    b_off[j] = OPA + rb * ROWB;
+    b_sw[j] = (rb >> 2) & 3;
+  }
+  half8_t af[MI][2], bf[NJ][2];
+  auto load_frags = [&](int stage) {
+    const char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i][s] = *reinterpret_cast<const half8_t*>(sb + a_off[i] + (((s * 2 + fhi) ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j][s] = *reinterpret_cast<const half8_t*>(sb + b_off[j] + (((s * 2 + fhi) ^ b_sw[j]) << 4));
+    }
+  };
+  auto mfma_tile = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // GEGLU epilogue of tile i, straight from the accumulators (see gemm_pp_kernel)
+  auto epilogue = [&](int i_tile) {
+    int m0, n0;
+    tile_origin(i_tile, m0, n0);
+    const int lc = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < NJ / 2; ++q) {
+      const int nc = n0 + wn * (32 * NJ) + q * 64;
+      half4_t bh[4], bg[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bh[g] = half4_t{0, 0, 0, 0};
+        bg[g] = half4_t{0, 0, 0, 0};
+        if (p.bias) {
+          bh[g] = *reinterpret_cast<const half4_t*>(p.bias + nc + 8 * g + 4 * hi);
+          bg[g] = *reinterpret_cast<const half4_t*>(p.bias + nc + 32 + 8 * g + 4 * hi);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + lc;
+        const int mc = m < p.M ? m : p.M - 1;
+        geglu_store32(acc[i][2 * q], acc[i][2 * q + 1], bh, bg, p.C + (size_t)mc * p.ldc + (nc >> 1), hi, m < p.M);
+      }
+    }
+  };
+
+  // The stores of an epilogue also count in vmcnt and are not ordered against loads, so the FIRST wait after an epilogue
+  // drains everything (vmcnt(0): the stores are a slot old by then, the two youngest K tiles are made to land early --
+  // once per output tile); every other wait is counted as in gemm_pp_kernel.
+  bool drain = false;
+  auto wait_landed = [&](int tiles_behind) {
+    if (drain) {
+      wait_vmcnt<0>();
+      drain = false;
+    } else {
+      pp_wait_tiles<2 * G, G>(tiles_behind);
+    }
+  };
+#pragma unroll 1
+  for (int s = 0; s < 3; ++s)
+    if (s < T) issue_next();
+  pp_wait_tiles<2 * G, G>(T - 1);
+  __builtin_amdgcn_s_barrier();                                     // B0
+  int kt = 0, ct = 0;
+  if (grp == 0) {
+#pragma unroll 1
+    for (int g = 0; g < T; ++g) {
+      if (kt == 0) {
+        if (g > 0) {
+          epilogue(ct++);                                           // previous tile, concurrent with group 1's (slot 2g)
+          drain = true;
+        }
+        zero_acc();
+      }
+      load_frags(g & 3);
+      if (g + 3 < T) issue_next();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                 // B(2g+1)
+      mfma_tile();
+      wait_landed(T - 2 - g);
+      __builtin_amdgcn_s_barrier();                                 // B(2g+2)
+      if (++kt == nk) kt = 0;
+    }
+    epilogue(ct);
+  } else {
+    __builtin_amdgcn_s_barrier();                                   // B1
+#pragma unroll 1
+    for (int g = 0; g < T; ++g) {
+      if (kt == 0) zero_acc();
+      load_frags(g & 3);
+      if (g + 3 < T) issue_next();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_landed(T - 2 - g);
+      __builtin_amdgcn_s_barrier();                                 // B(2g+2)
+      mfma_tile();
+      if (++kt == nk) {
+        kt = 0;
+        epilogue(ct++);
+        drain = true;
+      }
+      if (g < T - 1) __builtin_amdgcn_s_barrier();                  // B(2g+3)
+    }
+  }
+}
+
+static void launch_ppg(GemmParams& p, hipStream_t stream) {
+  constexpr size_t smem = (size_t)4 * (256 + 256) * 64;
+  static bool attr_set = false;
+  static int ncu = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0 || (ncu & 7)) ncu = 256;
+    attr_set = true;
+  }
+  p.tiles_n = p.N / 256;
+  p.tiles_total = cdiv(p.M, 256) * p.tiles_n;
+  const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
+  hipLaunchKernelGGL(gemm_ppg_kernel, dim3(grid), dim3(512), smem, stream, p);
 }

@@ -67,7 +67,8 @@ wide = rnd(M, 2 * K, seed=8)
 check("lda", lambda: ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t())
 
 # GEGLU (256-column tiles)
-for M, K, inner in [(200, 128, 256), (1500, 320, 1280), (300, 1280, 512)]:
+# (the last two cases give the persistent GEGLU kernel 2-3 output tiles per workgroup, one of them ragged in M)
+for M, K, inner in [(200, 128, 256), (1500, 320, 1280), (300, 1280, 512), (10240, 128, 1024), (20000, 320, 1024)]:
     a = rnd(M, K, seed=11)
     w, b = rnd(2 * inner, K, seed=12, scale=K ** -0.5), rnd(2 * inner, seed=13)
     hg = a.float() @ w.float().t() + b.float()
