@@ -87,3 +87,31 @@ def test_hot_path_refuses_cpu_tensors_and_odd_latents():
     _UNetBase._check_latent_size(96, 96, 4)
     with pytest.raises(AssertionError):
         den.forward(torch.zeros(1, 4, 16, 16), 0, torch.zeros(1, 5, 64))       # 5-D input required (transformer_3d.py:117-119)
+
+
+def test_zero_context_detection_and_pe_fold_tables():
+    """Host-side logic of two result-preserving shortcuts (no kernels involved): which leading frames have an all-zero
+    context (cross-attention == to_out bias there), and the per-frame row term pe @ Wq^T that replaces the query-only
+    positional-encoding add of the motion module (reference src/models/motion_module.py:416-417)."""
+    import torch
+    from mikudance_amd import UNet3DConditionModel
+    from mikudance_amd.blocks import MotionModule
+    from mikudance_amd.selftest import MM_KWARGS, SMALL
+    den = UNet3DConditionModel(sample_size=16, **SMALL, **MM_KWARGS)
+    ctx = torch.zeros(2, 5, 64)
+    ctx[1] = torch.randn(5, 64)
+    assert den._cross(ctx, [0] * 3 + [1] * 3, "cpu").zero_frames == 3                 # [uncond x3 | cond x3]
+    assert den._cross(ctx, [1, 0, 1, 0], "cpu").zero_frames == 0                      # interleaved: no leading run
+    assert den._cross(ctx.flip(0), [0] * 3 + [1] * 3, "cpu").zero_frames == 0
+    assert den._cross(torch.zeros(2, 5, 64), [0, 0, 1, 1], "cpu").zero_frames == 4
+    mm = MotionModule(64, max_len=32).float()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for prm in mm.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * 0.1)
+    pk = mm._pack(torch.device("cpu"))
+    ab = mm.temporal_transformer.transformer_blocks[0].attention_blocks[1]
+    want = ab.pos_encoder.pe[0].float() @ ab.to_q.weight.float().t()
+    assert tuple(pk["peq1"].shape) == (32, 192) and float(pk["peq1"][:, 64:].abs().max()) == 0.0
+    assert torch.allclose(pk["peq1"][:, :64].float(), want, atol=2e-3, rtol=2e-3)
+    assert torch.equal(pk["qkv1"].float()[64:128], ab.to_k.weight.half().float())
