@@ -65,6 +65,16 @@ def tokens(x):
     return x.view(-1, x.shape[-1])
 
 
+def groupnorm_frames(x, w, b, eps, silu, gn_frames=1):
+    """GroupNorm(32) of (B,H,W,C) frames; gn_frames consecutive frames share their statistics (frames of a clip-half are
+    contiguous, so the cross-frame form is the same kernel on the (B/gn_frames, gn_frames*H*W, C) view)."""
+    if gn_frames <= 1:
+        return ops.groupnorm(x, w, b, GROUPS, eps, silu=silu)
+    B, H, W, C = x.shape
+    assert B % gn_frames == 0
+    return ops.groupnorm(x.view(B // gn_frames, gn_frames * H * W, C), w, b, GROUPS, eps, silu=silu).view(x.shape)
+
+
 # ------------------------------------------------------------------------------------------------ ResnetBlock
 class ResnetBlock(_Packed):
     """ResnetBlock3D / diffusers ResnetBlock2D (reference src/models/resnet.py:123-247):
@@ -90,12 +100,14 @@ class ResnetBlock(_Packed):
             pk["scb"] = packing.vec(self.conv_shortcut.bias, dev)
         return pk
 
-    def forward(self, x, temb, rows_per_group):
-        """x (B,H,W,cin); temb [groups, cout] = time_emb_proj(silu(emb)) rows (already projected, see TimeEmbedding)."""
+    def forward(self, x, temb, rows_per_group, gn_frames=1):
+        """x (B,H,W,cin); temb [groups, cout] = time_emb_proj(silu(emb)) rows (already projected, see TimeEmbedding).
+        gn_frames > 1: GroupNorm statistics run over that many consecutive frames (the reference's plain nn.GroupNorm on
+        the 5-D tensor when use_inflated_groupnorm=False, src/models/resnet.py:156-191); 1 = per frame (InflatedGroupNorm)."""
         pk = self.packed()
-        h = ops.groupnorm(x, pk["n1w"], pk["n1b"], GROUPS, self.eps, silu=True)
+        h = groupnorm_frames(x, pk["n1w"], pk["n1b"], self.eps, True, gn_frames)
         h = ops.conv3x3(h, pk["c1"], self.cout, bias=pk["c1b"], rowadd=temb, rows_per_group=rows_per_group)
-        h = ops.groupnorm(h, pk["n2w"], pk["n2b"], GROUPS, self.eps, silu=True)
+        h = groupnorm_frames(h, pk["n2w"], pk["n2b"], self.eps, True, gn_frames)
         if self.conv_shortcut is not None:
             sc = ops.gemm(tokens(x), pk["sc"], bias=pk["scb"]).view(x.shape[:-1] + (self.cout,))
         else:
@@ -115,9 +127,15 @@ class ConvSampler(_Packed):
     def _pack(self, dev):
         return dict(w=packing.conv3x3_weight(self.conv.weight, dev), b=packing.vec(self.conv.bias, dev))
 
-    def forward(self, x):
+    def forward(self, x, size=None):
+        """size=(h, w): forced nearest-resize target (the reference's `upsample_size` for latents that are not a multiple of
+        2**levels, src/models/unet_3d_mix.py:447-455,564-586); the exact 2x case stays folded into the conv's addressing."""
         pk = self.packed()
         if self.up:
+            B, H, W, C = x.shape
+            if size is not None and tuple(size) != (2 * H, 2 * W):
+                x = ops.pack_nhwc(x, B, 1, (H * W * C, 0, 1, W * C, C), 0, C, C, size[0], size[1], hin=H, win=W)
+                return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"])
             return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], upsample=True)
         return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], stride=2)
 
@@ -164,8 +182,8 @@ class CrossContext:
     frame to its context batch, Lk valid tokens, Lpad stride.  K/V projections of the context are cached per block
     (step-invariant; SURVEY.md 2.2 'cross k/v')."""
 
-    def __init__(self, ctx, index, lk, lpad, key, zero_frames=0):
-        self.ctx, self.index, self.lk, self.lpad, self.key = ctx, index, lk, lpad, key
+    def __init__(self, ctx, index, lk, lpad, zero_frames=0):
+        self.ctx, self.index, self.lk, self.lpad = ctx, index, lk, lpad
         # leading frames whose context is all zeros (the CFG unconditional half: reference
         # src/pipelines/pipeline_mikudance.py:418-423 builds it with zeros_like).  For those rows K = V = 0 (to_k / to_v
         # have no bias), so the cross-attention output is exactly the to_out bias: see TransformerBlock.forward.
@@ -196,7 +214,7 @@ class TransformerBlock(_Packed):
         self.ref_mode = None
         self.ref_cfg = False
         self.stop_after_bank = False      # last writer block: everything after the bank write is dead code
-        self._kv_cache = {}
+        self._kv_cache = None             # (CrossContext object, K, V^T, {row tables}); matched with `is`, never by address
 
     def _pack(self, dev):
         L, V = packing.linear_weight, packing.vec
@@ -209,7 +227,7 @@ class TransformerBlock(_Packed):
         pk["q2"], pk["k2"], pk["v2"] = L(a2.to_q.weight, dev), L(a2.to_k.weight, dev), L(a2.to_v.weight, dev)
         pk["o2"], pk["o2b"] = L(a2.to_out[0].weight, dev), V(a2.to_out[0].bias, dev)
         _pack_ff(self.ff, dev, pk)
-        self._kv_cache = {}
+        self._kv_cache = None
         return pk
 
     def forward(self, h, B, L, cross):
@@ -245,11 +263,9 @@ class TransformerBlock(_Packed):
             q, k = qk[:, :C], qk[:, C:]
             vt = ops.gemm(n, pk["v1"], transpose_out=True)
         a = ops.attention(q, k, vt, B, H, D, L, L)
-        kv2 = self._kv_cache.get(cross.key)
-        if kv2 is None:
-            self._kv_cache.clear()
-            kv2 = (ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True), {})
-            self._kv_cache[cross.key] = kv2
+        if self._kv_cache is None or self._kv_cache[0] is not cross:
+            self._kv_cache = (cross, ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True), {})
+        kv2 = self._kv_cache[1:]
         zf = min(cross.zero_frames, B) if ZERO_CONTEXT_SKIP else 0
         if zf:
             # frames with an all-zero context: cross-attention == to_out bias.  It rides on the attn1 out-projection as a
@@ -332,6 +348,11 @@ class _TemporalTransformer(nn.Module):
         self.proj_in = Linear(dim, dim)
         self.transformer_blocks = nn.ModuleList([_TemporalBlock(dim, max_len)])
         self.proj_out = Linear(dim, dim)
+        # zero_module(proj_out) at construction (reference src/models/motion_module.py:73-76): what `mm_zero_proj_out=True`
+        # relies on when it drops the proj_out keys of the motion checkpoint.  Every other parameter is left unallocated-
+        # uninitialised (torch.empty): the loaders overwrite all of them.
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
 
 
 class MotionModule(_Packed):

@@ -74,11 +74,13 @@ extern "C" int md_concat_channels_f16(const void* a, int Ca, const void* b, int 
 }
 
 // ---- window accumulate: noise_sum[half][win[i]] += pred[half*f + i], counter[win[i]] += 1 -------------------------------
+// Frame slots of one window must be unique or -1 (skipped): blocks of different slots update disjoint rows without atomics.
 // pred: [(2 f) HW][4] fp16 (conv_out output, NHWC with 4 channels); noise_sum: [2][Ftot][HW][4] fp32; counter [Ftot] fp32
 __global__ void window_accumulate_kernel(const half_t* __restrict__ pred, float* __restrict__ noise_sum, float* __restrict__ counter,
                                          const int* __restrict__ win, int f, int Ftot, int HW4, int halves) {
   const int i = blockIdx.y;  // frame slot inside the window
   const int fr = win[i];
+  if (fr < 0) return;  // an earlier duplicate of a frame named twice by this window (host marks it: last occurrence wins)
   if (blockIdx.x == 0 && threadIdx.x == 0) counter[fr] += 1.f;
   for (int h = 0; h < halves; ++h) {
     const half_t* src = pred + (size_t)(h * f + i) * HW4;

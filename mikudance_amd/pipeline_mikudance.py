@@ -119,12 +119,22 @@ class MikuDanceVideoPipeline:
         counter = torch.zeros((F_,), device=dev, dtype=torch.float32)
         windows = [list(w) for w in get_context_scheduler(context_schedule)(0, num_inference_steps, F_, context_frames,
                                                                             context_stride, context_overlap)]
-        win_dev = [torch.tensor(w, dtype=torch.int32, device=dev) for w in windows]
+        mm_len = getattr(den, "temporal_position_encoding_max_len", None)
+        if mm_len is not None and max(len(w) for w in windows) > mm_len:
+            raise ValueError(f"windows of {max(len(w) for w in windows)} frames exceed the motion module's positional-encoding "
+                             f"table (temporal_position_encoding_max_len = {mm_len})")
+        # A wrapped, dilated window (context_stride >= 2, F < 2*size) can name a frame twice.  The reference's
+        # `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` (:662-666) is an index_put with duplicate indices: the LAST
+        # occurrence's value lands and the counter grows by one.  Earlier occurrences get slot -1 = "do not accumulate".
+        win_dev = [torch.tensor([fr if fr not in w[j + 1:] else -1 for j, fr in enumerate(w)], dtype=torch.int32, device=dev)
+                   for w in windows]
         win_long = [w.long() for w in win_dev]
         whole = len(windows) == 1 and windows[0] == list(range(F_))
         embeds = image_prompt_embeds
         bank_cache = {}
         refu.skip_dead_tail = True
+        den.clear_context_cache()
+        refu.clear_context_cache()
         try:
             for step_i, t in enumerate(timesteps):
                 noise_sum.zero_()
@@ -156,6 +166,8 @@ class MikuDanceVideoPipeline:
             refu.skip_dead_tail = False
             reader.clear()
             writer.clear()
+            den.clear_context_cache()
+            refu.clear_context_cache()
         return self._latents_out(lat, latents)
 
     def _latents_out(self, lat, like):

@@ -120,12 +120,13 @@ class UNet2DConditionModel(_UNet2DBase):
         pk = self.packed()
         dev = x.device
         B, hh, ww, _ = x.shape
-        self._check_latent_size(hh, ww, len(self.down_blocks))
+        force_size = self._needs_upsample_size(hh, ww, len(self.down_blocks))
         trows = self._time_rows(pk, torch.zeros(1), dev)                     # one group: every frame shares t = 0
         blocks = self.transformer_blocks_in_order()
-        last_writer = blocks[-1] if blocks and all(b.ref_mode == "write" for b in blocks) else None
+        # last bank writer in EXECUTION order (down -> mid -> up): the last attention of the last up block
+        last_writer = self.up_blocks[-1].attentions[-1].transformer_blocks[0] \
+            if blocks and all(b.ref_mode == "write" for b in blocks) else None
         # the sample after the LAST bank write is discarded by the pipeline: skip that dead tail (result preserving)
-        order = []
         x = ops.conv3x3(x, pk["cin"], self.conv_in.weight.shape[0], bias=pk["cinb"])
         skips = [x]
         for i, blk in enumerate(self.down_blocks):
@@ -158,7 +159,7 @@ class UNet2DConditionModel(_UNet2DBase):
                         return None
                     x = blk.attentions[j](x, cross)
             if blk.upsamplers is not None:
-                x = blk.upsamplers[0](x)
+                x = blk.upsamplers[0](x, skips[-1].shape[1:3] if force_size else None)
         return x
 
     skip_dead_tail = False

@@ -16,7 +16,7 @@ from torch import nn
 
 from . import ops, packing
 from .blocks import (Affine, Conv, ConvSampler, CrossContext, MotionModule, ResnetBlock, SpatialTransformer,
-                     TimestepEmbedding, _Packed, timestep_sinusoid, tokens)
+                     TimestepEmbedding, _Packed, groupnorm_frames, timestep_sinusoid, tokens)
 
 
 @dataclass
@@ -148,23 +148,39 @@ class _UNetBase(_Packed):
         return trows[:, a:a + n]
 
     def _cross(self, ctx, index_list, dev):
-        """ctx: (nkv, L, D) any float dtype; index_list: per-frame context batch."""
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), tuple(index_list))
-        hit = self._cross_cache.get(key)
-        if hit is None:
-            self._cross_cache.clear()
-            nkv, L, D = ctx.shape
-            lpad = packing.pad_to(L, 8)
-            buf = torch.zeros((nkv, lpad, D), device=dev, dtype=torch.float16)
-            buf[:, :L] = ctx.to(device=dev, dtype=torch.float16)
-            zero_ctx = (buf == 0).flatten(1).all(1).tolist()              # one host sync per new context, not per step
-            zero_frames = 0
-            while zero_frames < len(index_list) and zero_ctx[index_list[zero_frames]]:
-                zero_frames += 1
-            hit = CrossContext(buf.view(nkv * lpad, D), torch.tensor(index_list, dtype=torch.int32, device=dev), L, lpad,
-                               key=key, zero_frames=zero_frames)
-            self._cross_cache[key] = hit
+        """ctx: (nkv, L, D) any float dtype; index_list: per-frame context batch.
+
+        The padded fp16 copy (and, per block, its K/V projections) is step-invariant and cached -- ONE entry.  Identity of
+        the source is never inferred from its address alone: the entry keeps a strong reference to the caller's tensor, so
+        its storage cannot be freed and handed to a different tensor while the entry lives, and `_version` (shared by all
+        views of a storage) catches in-place edits.  Blocks key their K/V cache on the CrossContext OBJECT (`is`)."""
+        index_list = tuple(index_list)
+        hit = self._cross_cache.get("entry")
+        if hit is not None and hit.src.data_ptr() == ctx.data_ptr() and hit.src_version == ctx._version \
+                and hit.src.shape == ctx.shape and hit.src.stride() == ctx.stride() and hit.src.dtype == ctx.dtype \
+                and hit.src.device == ctx.device and hit.index_list == index_list:
+            return hit
+        self._cross_cache.clear()
+        nkv, L, D = ctx.shape
+        lpad = packing.pad_to(L, 8)
+        buf = torch.zeros((nkv, lpad, D), device=dev, dtype=torch.float16)
+        buf[:, :L] = ctx.to(device=dev, dtype=torch.float16)
+        zero_ctx = (buf == 0).flatten(1).all(1).tolist()              # one host sync per new context, not per step
+        zero_frames = 0
+        while zero_frames < len(index_list) and zero_ctx[index_list[zero_frames]]:
+            zero_frames += 1
+        hit = CrossContext(buf.view(nkv * lpad, D), torch.tensor(index_list, dtype=torch.int32, device=dev), L, lpad,
+                           zero_frames=zero_frames)
+        hit.src, hit.src_version, hit.index_list = ctx, ctx._version, index_list
+        self._cross_cache["entry"] = hit
         return hit
+
+    def clear_context_cache(self):
+        """Drop the cached cross-attention context and every block's K/V projections of it (called by the pipeline at the
+        start and end of each denoise(): nothing outlives a clip)."""
+        self._cross_cache.clear()
+        for tb in self.transformer_blocks_in_order():
+            tb._kv_cache = None
 
     def transformer_blocks_in_order(self):
         """DFS order of the reference's torch_dfs over (down, up, mid) -- see _build."""
@@ -183,11 +199,12 @@ class _UNetBase(_Packed):
         return self.conv_in.weight.device
 
     @staticmethod
-    def _check_latent_size(h, w, levels):
+    def _needs_upsample_size(h, w, levels):
+        """The reference's `forward_upsample_size` (src/models/unet_3d_mix.py:447-455, src/models/unet_2d_mix.py:1016-1027):
+        a latent that is not a multiple of 2**(levels-1) is still legal (any W, H % 8 == 0, scripts/inference_video.py:108);
+        each upsampler then resizes to the spatial size of the skip it is about to meet instead of exactly 2x."""
         m = 2 ** (levels - 1)
-        if h % m or w % m:
-            raise ValueError(f"latent size {h}x{w} must be a multiple of {m} (odd sizes need the reference's "
-                             f"`upsample_size` interpolation, not implemented)")
+        return bool(h % m or w % m)
 
 
 class UNet3DConditionModel(_UNetBase):
@@ -237,6 +254,8 @@ class UNet3DConditionModel(_UNetBase):
         self.in_channels = in_channels
         self.sample_size = sample_size
         self.mode = mode
+        self.temporal_position_encoding_max_len = mm_kwargs["max_len"] if use_motion_module else None
+        self.use_inflated_groupnorm = bool(use_inflated_groupnorm)
         self._build(in_channels, tuple(block_out_channels), cross_attention_dim, norm_eps, flags, mm_kwargs, with_out=True)
 
     # ------------------------------------------------------------------------------------------ internal NHWC forward
@@ -245,13 +264,14 @@ class UNet3DConditionModel(_UNetBase):
         pk = self.packed()
         dev = x.device
         _, hh, ww, _ = x.shape
-        self._check_latent_size(hh, ww, len(self.down_blocks))
+        force_size = self._needs_upsample_size(hh, ww, len(self.down_blocks))
         trows = self._time_rows(pk, timesteps, dev)                         # [nb, sumC]
+        gf = 1 if self.use_inflated_groupnorm else f                        # plain nn.GroupNorm on 5-D: stats across frames
         x = ops.conv3x3(x, pk["cin"], self.conv_in.weight.shape[0], bias=pk["cinb"])
         skips = [x]
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
-                x = r(x, self._temb(pk, trows, r), f * x.shape[1] * x.shape[2])
+                x = r(x, self._temb(pk, trows, r), f * x.shape[1] * x.shape[2], gf)
                 if blk.has_cross_attention:
                     x = blk.attentions[j](x, cross)
                 if blk.motion_modules[j] is not None:
@@ -261,22 +281,22 @@ class UNet3DConditionModel(_UNetBase):
                 x = blk.downsamplers[0](x)
                 skips.append(x)
         mb = self.mid_block
-        x = mb.resnets[0](x, self._temb(pk, trows, mb.resnets[0]), f * x.shape[1] * x.shape[2])
+        x = mb.resnets[0](x, self._temb(pk, trows, mb.resnets[0]), f * x.shape[1] * x.shape[2], gf)
         x = mb.attentions[0](x, cross)
         if mb.motion_modules[0] is not None:
             x = mb.motion_modules[0](x, nb, f)
-        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), f * x.shape[1] * x.shape[2])
+        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), f * x.shape[1] * x.shape[2], gf)
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 x = ops.concat_channels(x, skips.pop())
-                x = r(x, self._temb(pk, trows, r), f * x.shape[1] * x.shape[2])
+                x = r(x, self._temb(pk, trows, r), f * x.shape[1] * x.shape[2], gf)
                 if blk.has_cross_attention:
                     x = blk.attentions[j](x, cross)
                 if blk.motion_modules[j] is not None:
                     x = blk.motion_modules[j](x, nb, f)
             if blk.upsamplers is not None:
-                x = blk.upsamplers[0](x)
-        x = ops.groupnorm(x, pk["ow"], pk["ob"], 32, self.norm_eps, silu=True)
+                x = blk.upsamplers[0](x, skips[-1].shape[1:3] if force_size else None)
+        x = groupnorm_frames(x, pk["ow"], pk["ob"], self.norm_eps, True, gf)
         return tokens(ops.conv3x3(x, pk["co"], 4, bias=pk["cob"]))
 
     # ------------------------------------------------------------------------------------------ reference-compatible forward

@@ -24,6 +24,10 @@ class WindowLayout:
 
     def __init__(self, frames: int, size: int, max_levels: int, overlap: int, wrap: bool = True):
         self.frames, self.size, self.overlap, self.wrap = frames, size, overlap, wrap
+        if frames > size and size - overlap <= 0:
+            # the reference's range() would be given a step <= 0 here (src/pipelines/context.py:33-37): ValueError for 0,
+            # an empty schedule (then a 0/0 average) for a negative one -- refuse both up front
+            raise ValueError(f"context_overlap ({overlap}) must be smaller than context_frames ({size})")
         self.levels = 0 if frames <= size else min(max_levels, int(math.ceil(math.log2(frames / size))) + 1)
 
     def at_step(self, step: int) -> List[List[int]]:

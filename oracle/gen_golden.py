@@ -209,6 +209,35 @@ def g8_fullwidth():
                "seed_inputs": 100, "seed_den": 1234, "seed_ref": 4321}, open(os.path.join(OUT, "g8_meta.json"), "w"))
 
 
+def g9_fullsize():
+    """FULL-WIDTH UNet pair at BASELINE configs[1] spatial size (96x96 latents = 768x768 pixels, Lq = Lk = 9216 at d = 40),
+    f = 2 frames, CFG: one evaluation with the reference's literal call pattern (pipeline_mikudance.py:626-660).  This is
+    the size at which the GPU build's automatic dispatch picks the ping-pong conv/GEMM kernels and the folded d=40
+    attention, so the HIP path is pinned to the reference's own modules at its benchmark shapes.  Only `pred` is stored."""
+    from src.models.mutual_mix_attention import ReferenceAttentionControl
+    ref, den, ref_sd, den_sd = build_unets(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1,
+                                       fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1,
+                                       fusion_blocks="full")
+    f, h, w = 2, 96, 96
+    latents, ref_latents, embeds = synth_inputs(f, h, w, ctx_len=257, ctx_dim=768, seed=100)
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        x = latents.repeat(2, 1, 1, 1, 1)
+        g = ref_latents.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w)
+        emb_in = embeds.repeat((f, 1, 1))
+        ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)
+        reader.update(writer)
+        pred = den(x, torch.tensor(601), encoder_hidden_states=emb_in[:2], return_dict=False)[0]
+    print("g9 pair evaluated in %.1f s" % (time.time() - t0))
+    save_file({"g9.pred": pred.half().contiguous()}, os.path.join(OUT, "g9_fullsize_pred.safetensors"))
+    json.dump({"checksum_den": checksum(den_sd), "checksum_ref": checksum(ref_sd), "timestep": 601, "frames": f, "latent": [h, w],
+               "seed_inputs": 100, "seed_den": 1234, "seed_ref": 4321, "stored": "fp16 rounding of the fp32 reference output"},
+              open(os.path.join(OUT, "g9_meta.json"), "w"))
+
+
 def g6_keys():
     ref, den, _, _ = build_unets()      # full SD-1.5 geometry (constructor defaults + cross_attention_dim 768)
     json.dump({"denoising_unet": {k: list(v.shape) for k, v in den.state_dict().items()},
@@ -236,5 +265,6 @@ if __name__ == "__main__":
     if "g6" in which: g6_keys()
     if "g7" in which: g7_ddim()
     if "g8" in which: g8_fullwidth()
+    if "g9" in which: g9_fullsize()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

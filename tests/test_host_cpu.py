@@ -115,3 +115,31 @@ def test_zero_context_detection_and_pe_fold_tables():
     assert tuple(pk["peq1"].shape) == (32, 192) and float(pk["peq1"][:, 64:].abs().max()) == 0.0
     assert torch.allclose(pk["peq1"][:, :64].float(), want, atol=2e-3, rtol=2e-3)
     assert torch.equal(pk["qkv1"].float()[64:128], ab.to_k.weight.half().float())
+
+
+def test_cross_context_cache_never_matches_by_address_alone():
+    """a freed context tensor's address is re-used by the next clip's tokens (same shape, _version 0).
+    The cache entry owns its source tensor, so that cannot produce a stale hit (runs on CPU: `_cross` is host logic)."""
+    with torch.device("meta"):
+        den = M.UNet3DConditionModel(sample_size=16, **SMALL, **MM_KWARGS)
+    idx = [0, 0, 1, 1]
+    for trial in range(50):
+        x = torch.cat([torch.zeros(1, 5, 64), torch.randn(1, 5, 64)], 0)
+        hit = den._cross(x, idx, "cpu")
+        assert torch.equal(hit.ctx.view(2, 8, 64)[:, :5].float(), x.half().float())
+        assert hit.zero_frames == 2 and den._cross(x, idx, "cpu") is hit and den._cross(x[:2], idx, "cpu") is hit
+        del x, hit
+    x = torch.randn(2, 5, 64)
+    h1 = den._cross(x, idx, "cpu")
+    x.add_(1.0)
+    assert den._cross(x, idx, "cpu") is not h1
+    den.clear_context_cache()
+    assert not den._cross_cache
+
+
+def test_window_layout_rejects_non_advancing_windows():
+    with pytest.raises(ValueError):
+        list(M.get_context_scheduler("uniform")(0, 20, 48, 30, 1, 30))
+    with pytest.raises(ValueError):
+        list(M.get_context_scheduler("uniform")(0, 20, 48, 8, 1, 12))
+    assert list(M.get_context_scheduler("uniform")(0, 20, 4, 8, 1, 12)) == [[0, 1, 2, 3]]     # one window: overlap unused

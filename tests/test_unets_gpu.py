@@ -159,6 +159,28 @@ def test_long_clip_windows_f30_vs_oracle(small):
         pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 1, 3.5, context_frames=33)
 
 
+def test_dilated_wrapping_window_with_repeated_frames_vs_oracle(small):
+    """context_stride = 2 with F < 2 * context_frames: the dilated level's window wraps and names frames 0..18 (even) TWICE
+    (0,2,..,38,0,2,..,18).  The reference's `noise_pred[:,:,c] = noise_pred[:,:,c] + pred` is an index_put with duplicate
+    indices -- the last occurrence lands, the counter grows by one -- and the HIP accumulate must do exactly that
+    (deterministically: the host marks the earlier duplicates as skipped)."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    from mikudance_amd import get_context_scheduler
+    from mikudance_amd.synth import synth_inputs
+    wins = list(get_context_scheduler("uniform")(0, 2, 40, 30, 2, 8))
+    assert any(len(set(w)) < len(w) for w in wins)
+    lat, rl, emb = synth_inputs(40, 16, 16, ctx_len=5, ctx_dim=64, seed=9)
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 2, guidance_scale=3.5, context_frames=30, context_stride=2,
+                              context_overlap=8, reduced=True)
+    args = (lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5)
+    kw = dict(context_frames=30, context_stride=2, context_overlap=8)
+    out = pipe.denoise(*args, **kw)
+    assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+    assert torch.equal(out, pipe.denoise(*args, **kw))
+
+
 def test_config1_full_width_vs_oracle():
     """BASELINE configs[0] geometry (256x256 -> 32x32 latents, 4 frames, CFG) with the FULL-WIDTH SD-1.5 UNets
     (head dims 40/80/160, 320..1280 channels, 257x768 context): 2 DDIM steps on the GPU vs the fp32 CPU oracle."""
