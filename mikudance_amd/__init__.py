@@ -3,10 +3,12 @@
 Public surface (mirrors the reference's Python API for the hot path):
     UNet3DConditionModel, UNet2DConditionModel (+ UNet2DConditionModelPlain donor), ReferenceAttentionControl,
     DDIMScheduler, MikuDanceVideoPipeline, Pose2VideoPipeline, get_context_scheduler, camera_to_scene_motion,
-    AutoencoderKL (the next row after the loop: VAE encode / decode on the same kernels)
+    AutoencoderKL, CLIPVisionModelWithProjection (the rows after the loop: VAE encode / decode and the CLIP image tower on
+    the same kernels)
 All compute goes through libmdance_hip.so (include/mdance_hip.h); importing the package needs neither a GPU nor the
 library, calling any op does.
 """
+from .clip_vision import CLIPVisionModelWithProjection, clip_preprocess  # noqa: F401
 from .context import get_context_scheduler  # noqa: F401
 from .mutual_mix_attention import ReferenceAttentionControl  # noqa: F401
 from .pipeline_mikudance import MikuDanceVideoPipeline, MikuDanceVideoPipelineOutput  # noqa: F401

@@ -29,7 +29,7 @@
 #include <stdlib.h>
 
 
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3, ACT_QUICKGELU = 4 };  // 4: x * sigmoid(1.702 x) (CLIP)
 
 struct GemmParams {
   const half_t* A;
@@ -415,6 +415,9 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
         } else if (p.act == ACT_RELU) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (p.act == ACT_QUICKGELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
         }
         half_t* dst = p.C + (size_t)m * p.ldc + n;
         const bool vec = nvec && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
@@ -472,6 +475,35 @@ static int env_int(const char* name, int dflt) {
 }
 
 #include "gemm_pp.h"
+#include "gemm_ws.h"
+
+template <int KS, int CB>
+static void launch_ws(const GemmParams& g, hipStream_t stream) {
+  using Cfg = WsCfg<KS, CB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wsgemm_kernel<KS, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    attr_set = true;
+  }
+  WsParams p;
+  p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = g.residual; p.rowadd = g.rowadd;
+  p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr; p.ldra = g.ldra; p.M = g.M; p.N = g.N; p.rows_per_group = g.rows_per_group;
+  p.groups = g.N / Cfg::GC;
+  p.spx = 32 / p.groups;
+  p.streams = 8 * p.spx;
+  hipLaunchKernelGGL((wsgemm_kernel<KS, CB>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+}
+
+// W-stationary streaming kernel (gemm_ws.h): plain epilogues, K = 320 (N % 320 == 0) or K = 640 (N % 128 == 0), long M.
+static bool ws_eligible(const GemmParams& p) {
+  if (p.act != ACT_NONE || p.transpose_out || p.M < 32768) return false;
+  const bool k320 = p.K == 320 && p.N % 320 == 0 && p.N / 320 <= 8;
+  const bool k640 = p.K == 640 && p.N % 128 == 0 && p.N / 128 <= 16;
+  if (!k320 && !k640) return false;
+  if (p.lda % 8 || p.ldc % 8 || (p.residual && p.ldr % 8) || (p.rowadd && p.ldra % 8)) return false;
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return al(p.A) && al(p.W) && al(p.C) && al(p.bias) && al(p.residual) && al(p.rowadd);
+}
 
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
@@ -486,6 +518,15 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // loop long enough to amortise its prologue / epilogue, which no other workgroup covers.  Same-box A/B on MI355X:
   // +25..28 % on the 96x96 convs (950-1000 TF), +16 % on M=294912 N=320 K=1280, +3..6 % on the K >= 640 GEGLU GEMMs and the
   // 48x48 convs with K >= 5760; slower on the 24x24 / 12x12 levels (288 / 72 tiles) and on K = 320.
+  if constexpr (!CONV && !GEGLU) {
+    static int ws = -1;
+    if (ws < 0) ws = env_int("MD_GEMM_WS", 2);      // 0: off, 1: K = 320, 2: K = 320 and K = 640
+    if (ws > 0 && ws_eligible(p) && (p.K == 320 || ws >= 2)) {
+      if (p.K == 320) launch_ws<10, 5>(p, stream);
+      else launch_ws<20, 2>(p, stream);
+      return;
+    }
+  }
   if (pp > 0 && pp_eligible<CONV, GEGLU>(p)) {
     const long tiles = (long)cdiv(p.M, 256) * (p.N / (GEGLU ? 256 : 320));
     const long rounds = (tiles + 255) / 256;

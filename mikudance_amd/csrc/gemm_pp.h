@@ -355,6 +355,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       } else if (p.act == ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      } else if (p.act == ACT_QUICKGELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
       }
       if (p.residual) {
 #pragma unroll

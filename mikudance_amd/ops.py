@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU, ACT_QUICKGELU = 0, 1, 2, 3, 4
 F16 = torch.float16
 
 

@@ -2,9 +2,9 @@
 loop (:573-686) runs on the MI355X-native UNets / HIP kernels of this package.
 
 `__call__` keeps the reference signature and call order (CLIP embed -> VAE-encode every condition image -> 22-channel
-guidance tensor -> loop -> VAE decode).  The VAE and the CLIP vision tower are the caller's torch modules
-(`vae.encode(x).latent_dist.mean`, `vae.decode(z).sample`, `image_encoder(...)`) exactly as in the reference: they
-are per-clip constant cost outside the hot path ("next").  `denoise()` is the hot path itself on
+guidance tensor -> loop -> VAE decode).  The VAE and the CLIP vision tower are whatever modules the caller passes
+(`vae.encode(x).latent_dist.mean`, `vae.decode(z).sample`, `image_encoder(...)`) exactly as in the reference --
+mikudance_amd.AutoencoderKL / mikudance_amd.CLIPVisionModelWithProjection run them on the same HIP kernels.  `denoise()` is the hot path itself on
 tensors and is what bench.py and the parity tests drive.
 
 Result-preserving reductions (proven identical on the CPU oracle in tests/test_oracle.py):
@@ -128,7 +128,7 @@ class MikuDanceVideoPipeline:
         # occurrence's value lands and the counter grows by one.  Earlier occurrences get slot -1 = "do not accumulate".
         win_dev = [torch.tensor([fr if fr not in w[j + 1:] else -1 for j, fr in enumerate(w)], dtype=torch.int32, device=dev)
                    for w in windows]
-        win_long = [w.long() for w in win_dev]
+        win_long = [torch.tensor(w, dtype=torch.long, device=dev) for w in windows]     # gather indices: the real frames
         whole = len(windows) == 1 and windows[0] == list(range(F_))
         embeds = image_prompt_embeds
         bank_cache = {}
@@ -230,11 +230,16 @@ class MikuDanceVideoPipeline:
         return video.cpu().float().numpy()
 
     def clip_embeds(self, ref_image):
-        """reference :406-416 -- all 257 tokens: last_hidden_state -> post_layernorm -> visual_projection."""
-        from transformers import CLIPImageProcessor
-        clip_image = CLIPImageProcessor().preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+        """reference :406-416 -- all 257 tokens: last_hidden_state -> post_layernorm -> visual_projection.
+        `image_encoder` is mikudance_amd.CLIPVisionModelWithProjection (HIP kernels) or any module with the transformers
+        surface (`(pixel_values).last_hidden_state`, `.vision_model.post_layernorm`, `.visual_projection`)."""
+        from .clip_vision import clip_preprocess
+        clip_image = clip_preprocess(ref_image.resize((224, 224)))             # == CLIPImageProcessor().preprocess(...).pixel_values
         enc = self.image_encoder
-        emb = enc(clip_image.to(self._device, dtype=enc.dtype)).last_hidden_state
+        px = clip_image.to(self._device, dtype=enc.dtype)
+        if hasattr(enc, "image_prompt_embeds"):
+            return enc.image_prompt_embeds(px)
+        emb = enc(px).last_hidden_state
         return enc.visual_projection(enc.vision_model.post_layernorm(emb))
 
     # ------------------------------------------------------------------------------------------ reference-compatible call

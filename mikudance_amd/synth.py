@@ -13,8 +13,8 @@ def _is_norm_weight(key):
     if parts[-1] != "weight":
         return False
     owner = parts[-2]
-    if owner.startswith("norm") or owner in ("ff_norm", "conv_norm_out"):
-        return True
+    if owner.startswith("norm") or owner in ("ff_norm", "conv_norm_out") or "norm" in owner:
+        return True                                            # incl. CLIP's layer_norm1/2, pre_layrnorm, post_layernorm; VAE group_norm
     return len(parts) >= 3 and parts[-3] == "norms"          # motion module `norms.{0,1}.weight`
 
 

@@ -238,6 +238,73 @@ def g9_fullsize():
               open(os.path.join(OUT, "g9_meta.json"), "w"))
 
 
+def g10_odd_and_plain_gn():
+    """Two more evaluations of the reference's own UNet pair at reduced width (same seeds/weights as G4):
+    g10.pred_odd      latents 18 x 20 (not a multiple of 8): the `forward_upsample_size` / `upsample_size` path
+                      (src/models/unet_3d_mix.py:447-455,564-586; src/models/unet_2d_mix.py:1016-1027,1345-1346), f = 3, CFG
+    g10.pred_plain_gn use_inflated_groupnorm=False: torch.nn.GroupNorm on the 5-D tensor, i.e. statistics ACROSS the frames
+                      of a clip-half in every ResnetBlock3D and in conv_norm_out (src/models/resnet.py:156-191), 16 x 16, f = 4"""
+    from src.models.mutual_mix_attention import ReferenceAttentionControl
+    from src.models.unet_3d_mix import UNet3DConditionModel
+    t = {}
+
+    def pair(ref, den, f, h, w, seed):
+        writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+        reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
+        latents, ref_latents, embeds = synth_inputs(f, h, w, ctx_len=5, ctx_dim=64, seed=seed)
+        x = latents.repeat(2, 1, 1, 1, 1)
+        g = ref_latents.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w)
+        emb_in = embeds.repeat((f, 1, 1))
+        ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)
+        reader.update(writer)
+        pred = den(x, torch.tensor(601), encoder_hidden_states=emb_in[:2], return_dict=False)[0]
+        reader.clear(); writer.clear()
+        return pred.contiguous()
+
+    with torch.no_grad():
+        ref, den, ref_sd, den_sd = build_unets(**SMALL)
+        t["g10.pred_odd"] = pair(ref, den, 3, 18, 20, 31)
+        cfg = yaml.safe_load(open(os.path.join(REF, "configs/inference/mikudance_config.yaml")))["unet_additional_kwargs"]
+        cfg["use_inflated_groupnorm"] = False
+        den2 = UNet3DConditionModel(sample_size=16, **SMALL, **cfg).eval()
+        den2.load_state_dict(den_sd, strict=True)
+        t["g10.pred_plain_gn"] = pair(ref, den2, 4, 16, 16, 32)
+    save_file(t, os.path.join(OUT, "g10_odd_plain_gn.safetensors"))
+    json.dump({"odd": {"frames": 3, "latent": [18, 20], "seed_inputs": 31}, "plain_gn": {"frames": 4, "latent": [16, 16], "seed_inputs": 32},
+               "timestep": 601, "seed_den": 1234, "seed_ref": 4321, "checksum_den": checksum(den_sd), "checksum_ref": checksum(ref_sd)},
+              open(os.path.join(OUT, "g10_meta.json"), "w"))
+
+
+CLIP_SMALL = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, image_size=56, patch_size=14,
+                  projection_dim=64, hidden_act="quick_gelu")
+CLIP_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224, patch_size=14,
+                projection_dim=768, hidden_act="quick_gelu")       # the image_encoder of sd-image-variations (ViT-L/14)
+
+
+def g11_clip():
+    """transformers' OWN CLIPVisionModelWithProjection (installed in the build container; third party, not in /root/reference)
+    with seeded synthetic weights, driven exactly like src/pipelines/pipeline_mikudance.py:406-416:
+    last_hidden_state -> vision_model.post_layernorm -> visual_projection, all tokens.  Two geometries: a reduced one (fp32
+    tensors stored in full) and ViT-L/14 at 224x224 (257 x 768 output stored as fp16)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    t, meta = {}, {}
+    for name, geom, seed in (("small", CLIP_SMALL, 21), ("l14", CLIP_L14, 22)):
+        m = CLIPVisionModelWithProjection(CLIPVisionConfig(**geom)).eval()
+        sd = fill(m, seed)
+        g = torch.Generator().manual_seed(seed + 100)
+        px = torch.randn(1, 3, geom["image_size"], geom["image_size"], generator=g)
+        with torch.no_grad():
+            last = m(px).last_hidden_state
+            out = m.visual_projection(m.vision_model.post_layernorm(last))
+        t[f"g11.{name}.embeds"] = out.half().contiguous() if name == "l14" else out.contiguous()
+        if name == "small":
+            t["g11.small.last_hidden_state"] = last.contiguous()
+        meta[name] = {"config": geom, "seed_weights": seed, "seed_pixels": seed + 100, "checksum": checksum(sd),
+                      "keys": {k: list(v.shape) for k, v in sd.items()} if name == "small" else len(sd)}
+    save_file(t, os.path.join(OUT, "g11_clip.safetensors"))
+    json.dump(meta, open(os.path.join(OUT, "g11_meta.json"), "w"))
+
+
 def g6_keys():
     ref, den, _, _ = build_unets()      # full SD-1.5 geometry (constructor defaults + cross_attention_dim 768)
     json.dump({"denoising_unet": {k: list(v.shape) for k, v in den.state_dict().items()},
@@ -257,7 +324,7 @@ def g7_ddim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11"]
     if "g1" in which: g1_windows()
     if "g2" in which: g2_scene_motion()
     if "g3" in which: g3_blocks()
@@ -266,5 +333,7 @@ if __name__ == "__main__":
     if "g7" in which: g7_ddim()
     if "g8" in which: g8_fullwidth()
     if "g9" in which: g9_fullsize()
+    if "g10" in which: g10_odd_and_plain_gn()
+    if "g11" in which: g11_clip()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -74,7 +74,7 @@ def test_scene_motion_matches_reference(golden_dir):
     assert np.abs(camera_to_scene_motion(eye, eye, list(z["K"]), np.zeros((1, 24, 24)), 24, 24, False)).max() == 0
 
 
-def test_hot_path_refuses_cpu_tensors_and_odd_latents():
+def test_hot_path_refuses_cpu_tensors_and_flags_odd_latents():
     from mikudance_amd.unet_3d_mix import _UNetBase
     with torch.device("meta"):
         den = M.UNet3DConditionModel(sample_size=16, **SMALL, **MM_KWARGS)
@@ -82,9 +82,8 @@ def test_hot_path_refuses_cpu_tensors_and_odd_latents():
     pipe = M.MikuDanceVideoPipeline(None, None, ref, den, M.DDIMScheduler(**SCHED_KWARGS))
     with pytest.raises(RuntimeError):
         pipe.denoise(torch.zeros(1, 4, 2, 16, 16), torch.zeros(1, 2, 22, 16, 16), torch.zeros(2, 5, 64), 1, 3.5)
-    with pytest.raises(ValueError):
-        _UNetBase._check_latent_size(12, 16, 4)          # 12 is not a multiple of 8: needs the reference's upsample_size path
-    _UNetBase._check_latent_size(96, 96, 4)
+    assert _UNetBase._needs_upsample_size(12, 16, 4)     # 12 is not a multiple of 8: the reference's upsample_size path
+    assert _UNetBase._needs_upsample_size(90, 96, 4) and not _UNetBase._needs_upsample_size(96, 128, 4)
     with pytest.raises(AssertionError):
         den.forward(torch.zeros(1, 4, 16, 16), 0, torch.zeros(1, 5, 64))       # 5-D input required (transformer_3d.py:117-119)
 
@@ -143,3 +142,22 @@ def test_window_layout_rejects_non_advancing_windows():
     with pytest.raises(ValueError):
         list(M.get_context_scheduler("uniform")(0, 20, 48, 8, 1, 12))
     assert list(M.get_context_scheduler("uniform")(0, 20, 4, 8, 1, 12)) == [[0, 1, 2, 3]]     # one window: overlap unused
+
+
+def test_clip_tower_key_layout_and_preprocess_match_transformers(golden_dir):
+    """The CLIP tower's state-dict keys == transformers' CLIPVisionModelWithProjection's (pinned in g11_meta.json by the
+    generator, which built the third-party model), and clip_preprocess == CLIPImageProcessor defaults (constants restated)."""
+    import numpy as np
+    from PIL import Image
+    meta = json.load(open(os.path.join(golden_dir, "g11_meta.json")))["small"]
+    with torch.device("meta"):
+        m = M.CLIPVisionModelWithProjection(meta["config"])
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["keys"]
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 255, (224, 224, 3), dtype=np.uint8))
+    px = M.clip_preprocess(img)
+    a = np.asarray(img).astype(np.float64) / 255.0
+    want = (a - np.array([0.48145466, 0.4578275, 0.40821073])) / np.array([0.26862954, 0.26130258, 0.27577711])
+    assert tuple(px.shape) == (1, 3, 224, 224) and np.abs(px[0].permute(1, 2, 0).numpy() - want).max() < 1e-5
+    assert tuple(M.clip_preprocess(img.resize((300, 260))).shape) == (1, 3, 224, 224)
+    with pytest.raises(NotImplementedError):
+        M.CLIPVisionModelWithProjection(dict(meta["config"], hidden_act="gelu"))

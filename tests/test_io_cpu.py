@@ -1,0 +1,206 @@
+"""CPU: the I/O + preprocessing adapters (mikudance_amd/io_utils.py) that stand in for omegaconf, PyAV, cv2,
+torchvision and scikit-image around scripts/inference_video.py, and the 22-channel guidance assembly (SURVEY.md 8 a15,
+src/pipelines/pipeline_mikudance.py:456-569) with a deterministic stand-in VAE."""
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import mikudance_amd as M
+from mikudance_amd import io_utils as U
+from mikudance_amd.selftest import MM_KWARGS, SCHED_KWARGS, SMALL
+
+REF_CFG = """
+pretrained_base_model_path: "./pretrained_weights/stable-diffusion-v1-5"
+weight_dtype: 'fp16'
+ref_depth_path: null
+tgt_face_path: "None"
+unet_additional_kwargs:
+  use_inflated_groupnorm: true
+  motion_module_resolutions:
+  - 1
+  - 2
+  motion_module_kwargs:
+    num_attention_heads: 8
+    attention_block_types:
+    - Temporal_Self
+    - Temporal_Self
+noise_scheduler_kwargs:
+  beta_start: 0.00085
+  rescale_betas_zero_snr: True
+"""
+
+
+def test_load_config_attribute_access_like_omegaconf(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text(REF_CFG)
+    cfg = U.load_config(p)
+    assert cfg.weight_dtype == "fp16" and cfg.ref_depth_path is None and cfg.tgt_face_path == "None"
+    assert cfg.unet_additional_kwargs.motion_module_kwargs.num_attention_heads == 8
+    assert cfg.unet_additional_kwargs.motion_module_resolutions == [1, 2]
+    kw = U.to_container(cfg.noise_scheduler_kwargs)
+    assert type(kw) is dict and kw == {"beta_start": 0.00085, "rescale_betas_zero_snr": True}
+    assert dict(**cfg.unet_additional_kwargs)["use_inflated_groupnorm"] is True          # `**cfg.section` as the loaders do
+    with pytest.raises(AttributeError):
+        cfg.nope
+
+
+def _frames(n=5, w=48, h=32, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 255, (h // 8, w // 8, 3), dtype=np.uint8)
+    out = []
+    for i in range(n):
+        a = np.kron(np.roll(base, i, axis=1), np.ones((8, 8, 1), dtype=np.uint8))      # blocky -> JPEG friendly
+        out.append(Image.fromarray(a.astype(np.uint8)))
+    return out
+
+
+def test_mp4_motion_jpeg_round_trip_and_fps(tmp_path):
+    frames = _frames()
+    p = str(tmp_path / "out" / "v.mp4")
+    U.save_videos_from_pil(frames, p, fps=Fraction(30000, 1001))
+    raw = open(p, "rb").read()
+    assert raw[4:8] == b"ftyp" and b"moov" in raw and b"jpeg" in raw
+    back = U.read_frames(p)
+    assert len(back) == len(frames) and back[0].size == frames[0].size
+    for a, b in zip(frames, back):
+        assert np.abs(np.asarray(a, dtype=np.int32) - np.asarray(b, dtype=np.int32)).mean() < 2.0      # JPEG q95 4:4:4
+    assert abs(float(U.get_fps(p)) - 29.97) < 0.01
+    U.save_videos_from_pil(frames, str(tmp_path / "i.mp4"), fps=8)
+    assert U.get_fps(str(tmp_path / "i.mp4")) == 8
+    with pytest.raises(ValueError):
+        U.save_videos_from_pil(frames, str(tmp_path / "v.avi"))
+
+
+def test_read_frames_other_containers(tmp_path):
+    frames = _frames(4)
+    U.save_videos_from_pil(frames, str(tmp_path / "v.gif"), fps=10)
+    g = U.read_frames(tmp_path / "v.gif")
+    assert len(g) == 4 and g[0].mode == "RGB" and U.get_fps(tmp_path / "v.gif") == 10
+    d = tmp_path / "dir"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        f.save(d / f"{i:04d}.png")
+    back = U.read_frames(d)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(frames, back))
+    np.save(tmp_path / "f.npy", np.stack([np.asarray(f) for f in frames]))
+    assert np.array_equal(np.asarray(U.read_frames(tmp_path / "f.npy")[2]), np.asarray(frames[2]))
+    # a video codec that needs an external decoder: a clear error, not garbage
+    raw = bytearray(open(_mp4(tmp_path, frames), "rb").read())
+    i = raw.index(b"jpeg", raw.index(b"stsd"))
+    raw[i:i + 4] = b"avc1"
+    open(tmp_path / "h264.mp4", "wb").write(raw)
+    with pytest.raises(RuntimeError, match="external decoder"):
+        U.read_frames(tmp_path / "h264.mp4")
+
+
+def _mp4(tmp_path, frames):
+    p = str(tmp_path / "tmp.mp4")
+    U.save_videos_from_pil(frames, p, fps=8)
+    return p
+
+
+def test_make_grid_and_save_videos_grid(tmp_path):
+    x = torch.arange(3 * 3 * 4 * 5, dtype=torch.float32).reshape(3, 3, 4, 5) / 200.0
+    g = U.make_grid(x, nrow=2)
+    assert tuple(g.shape) == (3, 2 * 6 + 2, 2 * 7 + 2)                   # 2 rows x 2 cols, padding 2
+    assert torch.equal(g[:, 2:6, 2:7], x[0]) and torch.equal(g[:, 2:6, 9:14], x[1]) and torch.equal(g[:, 8:12, 2:7], x[2])
+    assert float(g[:, :2].abs().max()) == 0 and float(g[:, 8:12, 9:14].abs().max()) == 0          # border / empty cell = pad_value
+    assert torch.equal(U.make_grid(x[:1]), x[0])
+    assert tuple(U.make_grid(x[:, :1], nrow=3).shape) == (3, 8, 23)      # single channel -> 3 channels
+    video = torch.rand(3, 3, 4, 16, 24)                                   # b c t h w, like cat([ref, pose, video]) of the script
+    p = str(tmp_path / "grid" / "g.mp4")
+    U.save_videos_grid(video, p, n_rows=3, fps=12)
+    back = U.read_frames(p)
+    assert len(back) == 4 and back[0].size == (3 * 26 + 2, 16 + 4) and U.get_fps(p) == 12
+    t = U.frames_to_tensor(back, 20, 80)
+    assert tuple(t.shape) == (1, 3, 4, 20, 80) and 0.0 <= float(t.min()) and float(t.max()) <= 1.0
+
+
+def test_resize_depth_properties():
+    rng = np.random.default_rng(1)
+    d = rng.uniform(0.2, 0.9, (1, 768, 768))
+    r = U.resize_depth(d, (1, 96, 96))
+    assert r.shape == (1, 96, 96) and d.min() <= r.min() and r.max() <= d.max()
+    assert abs(r.mean() - d.mean()) < 2e-3                                # anti-aliased average preserved
+    assert np.allclose(U.resize_depth(np.full((1, 64, 64), 0.37), (1, 8, 8)), 0.37)
+    ramp = np.tile(np.linspace(0, 1, 64)[None, None], (1, 64, 1))
+    rr = U.resize_depth(ramp, (1, 8, 8))
+    assert np.all(np.diff(rr[0, 0]) > 0) and np.allclose(rr[0, :, 3], rr[0, 0, 3])
+    assert np.array_equal(U.resize_depth(d, d.shape), d)
+    assert np.abs(U.resize_depth(np.zeros((1, 768, 768)), (1, 96, 96))).max() == 0     # `depth_map = np.zeros(...)` branch of the script
+
+
+class _RecordingVAE(torch.nn.Module):
+    """Deterministic stand-in for AutoencoderKL.encode: 8x average pooling of RGB -> 4 channels (+ the channel mean)."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    dtype = property(lambda self: self.p.dtype)
+    device = property(lambda self: self.p.device)
+
+    @staticmethod
+    def latent(x):
+        z = torch.nn.functional.avg_pool2d(x.float(), 8)
+        return torch.cat([z, z.mean(1, keepdim=True)], 1)
+
+    def encode(self, x):
+        return type("E", (), {"latent_dist": type("D", (), {"mean": self.latent(x)})})
+
+    def decode(self, z, **kw):
+        return type("S", (), {"sample": torch.nn.functional.interpolate(z[:, :3].float(), scale_factor=8.0, mode="nearest")})
+
+
+def test_guidance_tensor_assembly_values(golden_dir):
+    """a15: `ref_latents` handed to the loop == cat([ref_image, ref_skel, pose_t, face_t, hand_t, flow_t]) per frame, in that
+    channel order, with the reference's preprocessing (ref image in [-1, 1], condition images in [0, 1], Lanczos resize,
+    x 0.18215) and the scene-motion flow of REAL camera tracks (g2) through camera_to_scene_motion -- value for value."""
+    from mikudance_amd.scene_motion import camera_to_scene_motion
+    H = W = 64
+    F_ = 3
+    rng = np.random.default_rng(5)
+    img = lambda: Image.fromarray(rng.integers(0, 255, (80, 72, 3), dtype=np.uint8))
+    ref_image, ref_skel = img(), img()
+    pose, face, hand = [img() for _ in range(F_)], [img() for _ in range(F_)], [img() for _ in range(F_)]
+    z = np.load(os.path.join(golden_dir, "g2_scene_motion.npz"))
+    depth = U.resize_depth(np.kron(z["depth"], np.ones((1, 8, 8))), (1, H // 8, W // 8))
+    flow = camera_to_scene_motion(list(z["w2c"][:F_]), list(z["c2w"][:F_]), [3.2, 3.2, 1.6, 1.6], depth, W // 8, H // 8, False)
+    assert flow.shape == (F_, 2, 8, 8) and np.abs(flow[1:]).max() > 0
+
+    with torch.device("meta"):
+        den = M.UNet3DConditionModel(sample_size=16, **SMALL, **MM_KWARGS)
+        ref = M.UNet2DConditionModel(sample_size=16, **SMALL)
+    clip = type("C", (), {"dtype": torch.float32, "image_prompt_embeds": lambda self, px: torch.ones(1, 5, 64) * float(px.mean())})()
+    pipe = M.MikuDanceVideoPipeline(_RecordingVAE(), clip, ref, den, M.DDIMScheduler(**SCHED_KWARGS))
+    pipe._device = torch.device("cpu")
+    seen = {}
+
+    def fake_denoise(latents, ref_latents, embeds, *a, **k):
+        seen.update(latents=latents, ref_latents=ref_latents, embeds=embeds, args=a)
+        return latents
+
+    pipe.denoise = fake_denoise
+    out = pipe(ref_image, ref_skel, pose, face, hand, flow, W, H, F_, 2, 3.5, generator=torch.manual_seed(7))
+    rl = seen["ref_latents"]
+    assert tuple(rl.shape) == (1, F_, 22, H // 8, W // 8)
+
+    def prep(im, normalize):                                              # VaeImageProcessor.preprocess (:70-79, Appendix A)
+        a = np.asarray(im.convert("RGB").resize((W, H), resample=Image.LANCZOS), dtype=np.float32) / 255.0
+        t = torch.from_numpy(a).permute(2, 0, 1)[None]
+        return t * 2 - 1 if normalize else t
+
+    lat = lambda im, normalize: _RecordingVAE.latent(prep(im, normalize)) * 0.18215
+    for t in range(F_):
+        want = torch.cat([lat(ref_image, True), lat(ref_skel, False), lat(pose[t], False), lat(face[t], False), lat(hand[t], False),
+                          torch.from_numpy(flow[t:t + 1]).float()], dim=1)[0]
+        assert torch.allclose(rl[0, t].float(), want, atol=1e-6), t
+    # CFG context: [zeros, tokens]; initial noise from the caller's CPU generator (quirk 11)
+    assert tuple(seen["embeds"].shape) == (2, 5, 64) and float(seen["embeds"][0].abs().max()) == 0 and float(seen["embeds"][1].abs().min()) > 0
+    want_noise = torch.randn((1, 4, F_, H // 8, W // 8), generator=torch.manual_seed(7))
+    assert torch.equal(seen["latents"].float(), want_noise)
+    assert tuple(out.videos.shape) == (1, 3, F_, H, W) and out.videos.dtype == torch.float32

@@ -150,3 +150,37 @@ def test_g7_ddim(golden_dir):
     assert float(sch.alphas_cumprod[-1]) == 0.0          # zero terminal SNR
     x = torch.randn(2, 3); v = torch.randn(2, 3)
     assert torch.allclose(sch.step(v, 999, x), (sch.coeffs(999)[1] ** 0.5) * (-v) + ((1 - sch.coeffs(999)[1]) ** 0.5) * x)
+
+
+def test_g10_odd_latent_size_and_plain_groupnorm(small, golden_dir):
+    """The oracle against the reference's own modules on (i) an 18 x 20 latent (not a multiple of 8: `upsample_size` forces
+    every upsampler's output to the size of the skip it meets) and (ii) use_inflated_groupnorm=False (cross-frame statistics)."""
+    meta, ref_sd, den_sd, _ = small
+    g = load_file(os.path.join(golden_dir, "g10_odd_plain_gn.safetensors"))
+    m = json.load(open(os.path.join(golden_dir, "g10_meta.json")))
+    for name, key, kw in (("odd", "g10.pred_odd", {}), ("plain_gn", "g10.pred_plain_gn", {"inflated_groupnorm": False})):
+        f, (h, w) = m[name]["frames"], m[name]["latent"]
+        lat, rl, emb = synth_inputs(f, h, w, ctx_len=5, ctx_dim=64, seed=m[name]["seed_inputs"])
+        gin = rl.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w)
+        banks, _ = O.reference_unet_forward(ref_sd, gin, emb.repeat((f, 1, 1)))
+        banks = {k: v.half().float() for k, v in banks.items()}
+        pred = O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(m["timestep"]), emb, banks, cfg=True, **kw)
+        assert rel(pred, g[key]) < 1e-4, (name, rel(pred, g[key]))
+    # and the two GroupNorm flavours really differ
+    lat, rl, emb = synth_inputs(4, 16, 16, ctx_len=5, ctx_dim=64, seed=32)
+    a = O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(601), emb, None)
+    b = O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(601), emb, None, inflated_groupnorm=False)
+    assert rel(a, b) > 1e-2
+
+
+def test_g11_clip_restatement_vs_transformers_golden(golden_dir):
+    """oracle clip_image_prompt_embeds against transformers' own CLIPVisionModelWithProjection (g11), reduced geometry in full
+    fp32 and ViT-L/14 against the fp16-stored output."""
+    g = load_file(os.path.join(golden_dir, "g11_clip.safetensors"))
+    meta = json.load(open(os.path.join(golden_dir, "g11_meta.json")))
+    m = meta["small"]
+    sd = synth_state_dict(m["keys"], seed=m["seed_weights"])
+    px = torch.randn(1, 3, m["config"]["image_size"], m["config"]["image_size"], generator=torch.Generator().manual_seed(m["seed_pixels"]))
+    out, last = O.clip_image_prompt_embeds(sd, px, m["config"]["num_attention_heads"], m["config"]["patch_size"], return_hidden=True)
+    assert rel(last, g["g11.small.last_hidden_state"]) < 1e-4 and rel(out, g["g11.small.embeds"]) < 1e-4
+    assert tuple(out.shape) == (1, 17, 64)

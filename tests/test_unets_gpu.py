@@ -97,8 +97,6 @@ def test_non_square_latents_and_odd_frame_count_vs_oracle(small):
     out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5)
     assert out.shape == lat.shape
     assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
-    with pytest.raises(ValueError):            # latent sizes must be multiples of 8 (three stride-2 levels + skip concats)
-        pipe.denoise(lat[..., :20].cuda().half(), rl[..., :20].cuda().half(), emb.cuda().half(), 1, 3.5)
 
 
 def test_scheduler_step_api(small):
@@ -181,12 +179,36 @@ def test_dilated_wrapping_window_with_repeated_frames_vs_oracle(small):
     assert torch.equal(out, pipe.denoise(*args, **kw))
 
 
-def test_config1_full_width_vs_oracle():
+@pytest.fixture(scope="module")
+def full(golden_dir):
+    """FULL-WIDTH SD-1.5 geometry, seeded weights (checksums pinned by g8_meta.json), built once for the module."""
+    meta = json.load(open(os.path.join(golden_dir, "g8_meta.json")))
+    geom = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    ref, den, ref_sd, den_sd = build_models(geom=geom, seed_den=meta["seed_den"], seed_ref=meta["seed_ref"])
+    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
+    assert abs(cs(ref_sd) - meta["checksum_ref"]) < 1e-6 * meta["checksum_ref"]
+    return ref, den, ref_sd, den_sd
+
+
+def _literal_pair(ref, den, lat, rl, emb, f, h, w, timestep):
+    """One UNet-pair evaluation with the reference's literal call pattern (pipeline_mikudance.py:626-660)."""
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
+    g = rl.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w).cuda().half()
+    emb_in = emb.repeat((f, 1, 1)).cuda().half()
+    ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)
+    reader.update(writer)
+    pred = den(lat.repeat(2, 1, 1, 1, 1).cuda().half(), torch.tensor(timestep), encoder_hidden_states=emb_in[:2], return_dict=False)[0]
+    reader.clear(); writer.clear()
+    return pred
+
+
+def test_config1_full_width_vs_oracle(full):
     """BASELINE configs[0] geometry (256x256 -> 32x32 latents, 4 frames, CFG) with the FULL-WIDTH SD-1.5 UNets
     (head dims 40/80/160, 320..1280 channels, 257x768 context): 2 DDIM steps on the GPU vs the fp32 CPU oracle."""
     from mikudance_amd.synth import synth_inputs
-    full = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
-    ref, den, ref_sd, den_sd = build_models(geom=full)
+    ref, den, ref_sd, den_sd = full
     lat, rl, emb = synth_inputs(4, 32, 32, ctx_len=257, ctx_dim=768, seed=100)
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5)
@@ -196,32 +218,95 @@ def test_config1_full_width_vs_oracle():
     assert r < 3e-2 and c > 0.999, (r, c)
 
 
-def test_g8_full_width_unets_vs_reference_golden(golden_dir):
+def test_g8_full_width_unets_vs_reference_golden(full, golden_dir):
     """FULL-WIDTH UNets at configs[0] shape against the prediction of the reference's own modules
     (tests/golden/g8_fullwidth_pred.safetensors <- oracle/gen_golden.py g8): literal call pattern through the
     API-compatible forward()s, weights / inputs regenerated from their seeds (checksums pinned in g8_meta.json)."""
     from mikudance_amd.synth import synth_inputs
     meta = json.load(open(os.path.join(golden_dir, "g8_meta.json")))
     gold = load_file(os.path.join(golden_dir, "g8_fullwidth_pred.safetensors"))["g8.pred"]
-    full = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
-    ref, den, ref_sd, den_sd = build_models(geom=full, seed_den=meta["seed_den"], seed_ref=meta["seed_ref"])
-    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
-    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
-    assert abs(cs(ref_sd) - meta["checksum_ref"]) < 1e-6 * meta["checksum_ref"]
-    del ref_sd, den_sd
+    ref, den, _, _ = full
     f, (h, w) = meta["frames"], meta["latent"]
     lat, rl, emb = synth_inputs(f, h, w, ctx_len=257, ctx_dim=768, seed=meta["seed_inputs"])
-    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
-    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
-    g = rl.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w).cuda().half()
-    emb_in = emb.repeat((f, 1, 1)).cuda().half()
-    ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb_in, return_dict=False)
-    reader.update(writer)
-    pred = den(lat.repeat(2, 1, 1, 1, 1).cuda().half(), torch.tensor(meta["timestep"]), encoder_hidden_states=emb_in[:2],
-               return_dict=False)[0]
-    reader.clear(); writer.clear()
+    pred = _literal_pair(ref, den, lat, rl, emb, f, h, w, meta["timestep"])
     r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
     assert r < 3e-2 and c > 0.999, (r, c)
+
+
+def test_g9_full_size_unets_vs_reference_golden(full, golden_dir):
+    """The benchmark's OWN spatial size: full-width UNets at 96 x 96 latents (768 x 768 pixels; Lq = Lk = 9216 at d = 40,
+    2304 at d = 80, 576 at d = 160), f = 2, CFG, against the reference's own modules (g9 <- oracle/gen_golden.py g9).  With
+    the automatic dispatch this runs the kernels that only exist at this size -- the ping-pong conv / GEMM, the persistent
+    GEGLU GEMM, the FOLD attention over 144 key tiles -- so they are pinned to the reference, not to each other."""
+    from mikudance_amd.synth import synth_inputs
+    assert os.environ.get("MD_GEMM_PP", "2") == "2"                    # automatic kernel selection
+    meta = json.load(open(os.path.join(golden_dir, "g9_meta.json")))
+    gold = load_file(os.path.join(golden_dir, "g9_fullsize_pred.safetensors"))["g9.pred"].float()
+    ref, den, _, _ = full
+    f, (h, w) = meta["frames"], meta["latent"]
+    lat, rl, emb = synth_inputs(f, h, w, ctx_len=257, ctx_dim=768, seed=meta["seed_inputs"])
+    pred = _literal_pair(ref, den, lat, rl, emb, f, h, w, meta["timestep"])
+    r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
+    assert r < 3e-2 and c > 0.999, (r, c)
+
+
+def test_g9_full_size_pingpong_kernels_vs_reference_golden(golden_dir, tmp_path):
+    """Same G9 evaluation in a subprocess with MD_GEMM_PP=1: every eligible conv / GEMM / GEGLU GEMM takes the ping-pong
+    (and persistent ping-pong) kernels that the automatic dispatch reserves for >= 225-tile launches (B = 32 frames at
+    config 2; G9's B = 4 alone would not select them) -- pinned to the reference's own prediction, not to a sibling kernel."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "g9_pp.pt")
+    r = subprocess.run([sys.executable, os.path.join(here, "g9_pair.py"), out], env=dict(os.environ, MD_GEMM_PP="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    pred = torch.load(out)
+    gold = load_file(os.path.join(golden_dir, "g9_fullsize_pred.safetensors"))["g9.pred"].float()
+    r_, c = rel_l2(pred, gold), cosine(pred, gold)
+    assert r_ < 3e-2 and c > 0.999, (r_, c)
+
+
+def test_g10_odd_latent_size_vs_reference_golden(small, golden_dir):
+    """18 x 20 latents (144 x 160 pixels: a multiple of 8 as scripts/inference_video.py:108 demands, not of 64): every
+    upsampler resizes to the size of the skip it meets (`upsample_size`), token counts 360 / 90 / 25 / 9 per frame."""
+    from mikudance_amd.synth import synth_inputs
+    meta, ref, den, ref_sd, den_sd, t = small
+    m = json.load(open(os.path.join(golden_dir, "g10_meta.json")))
+    gold = load_file(os.path.join(golden_dir, "g10_odd_plain_gn.safetensors"))["g10.pred_odd"]
+    f, (h, w) = m["odd"]["frames"], m["odd"]["latent"]
+    lat, rl, emb = synth_inputs(f, h, w, ctx_len=5, ctx_dim=64, seed=m["odd"]["seed_inputs"])
+    pred = _literal_pair(ref, den, lat, rl, emb, f, h, w, m["timestep"])
+    r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    # and through the whole loop at another odd size vs the oracle
+    lat, rl, emb = synth_inputs(3, 12, 20, ctx_len=5, ctx_dim=64, seed=12)
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 2, guidance_scale=3.5, reduced=True)
+    out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 2, 3.5)
+    assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+
+
+def test_g10_plain_groupnorm_vs_reference_golden(small, golden_dir):
+    """use_inflated_groupnorm=False: GroupNorm statistics across the frames of a clip-half (torch.nn.GroupNorm on the 5-D
+    tensor in the reference, src/models/resnet.py:156-191) -- same weights as `small`, different constructor flag."""
+    from mikudance_amd import UNet3DConditionModel
+    from mikudance_amd.selftest import MM_KWARGS, SMALL
+    from mikudance_amd.synth import synth_inputs
+    meta, ref, den, ref_sd, den_sd, t = small
+    m = json.load(open(os.path.join(golden_dir, "g10_meta.json")))
+    gold = load_file(os.path.join(golden_dir, "g10_odd_plain_gn.safetensors"))["g10.pred_plain_gn"]
+    den2 = UNet3DConditionModel(sample_size=16, **SMALL, **dict(MM_KWARGS, use_inflated_groupnorm=False))
+    den2.load_state_dict(den_sd, strict=True)
+    den2 = den2.to(device="cuda", dtype=torch.float16)
+    f, (h, w) = m["plain_gn"]["frames"], m["plain_gn"]["latent"]
+    lat, rl, emb = synth_inputs(f, h, w, ctx_len=5, ctx_dim=64, seed=m["plain_gn"]["seed_inputs"])
+    pred = _literal_pair(ref, den2, lat, rl, emb, f, h, w, m["timestep"])
+    r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    pred_inflated = _literal_pair(ref, den, lat, rl, emb, f, h, w, m["timestep"])
+    assert rel_l2(pred_inflated.float(), gold) > 2 * r
 
 
 class _FakeVAE(torch.nn.Module):
