@@ -477,26 +477,35 @@ static int env_int(const char* name, int dflt) {
 #include "gemm_pp.h"
 #include "gemm_ws.h"
 
-template <int KS, int CB>
-static void launch_ws(const GemmParams& g, hipStream_t stream) {
+template <int KS, int CB, bool RES, bool RA>
+static void launch_ws_variant(const WsParams& p, hipStream_t stream) {
   using Cfg = WsCfg<KS, CB>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wsgemm_kernel<KS, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wsgemm_kernel<KS, CB, RES, RA>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
     attr_set = true;
   }
+  hipLaunchKernelGGL((wsgemm_kernel<KS, CB, RES, RA>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+}
+
+template <int KS, int CB>
+static void launch_ws(const GemmParams& g, hipStream_t stream) {
+  using Cfg = WsCfg<KS, CB>;
   WsParams p;
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = g.residual; p.rowadd = g.rowadd;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr; p.ldra = g.ldra; p.M = g.M; p.N = g.N; p.rows_per_group = g.rows_per_group;
   p.groups = g.N / Cfg::GC;
   p.spx = 32 / p.groups;
   p.streams = 8 * p.spx;
-  hipLaunchKernelGGL((wsgemm_kernel<KS, CB>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+  if (g.residual && g.rowadd) launch_ws_variant<KS, CB, true, true>(p, stream);
+  else if (g.residual) launch_ws_variant<KS, CB, true, false>(p, stream);
+  else if (g.rowadd) launch_ws_variant<KS, CB, false, true>(p, stream);
+  else launch_ws_variant<KS, CB, false, false>(p, stream);
 }
 
 // W-stationary streaming kernel (gemm_ws.h): plain epilogues, K = 320 (N % 320 == 0) or K = 640 (N % 128 == 0), long M.
 static bool ws_eligible(const GemmParams& p) {
-  if (p.act != ACT_NONE || p.transpose_out || p.M < 32768) return false;
+  if (p.act != ACT_NONE || p.transpose_out || p.M < 32768 || p.M % 16) return false;
   const bool k320 = p.K == 320 && p.N % 320 == 0 && p.N / 320 <= 8;
   const bool k640 = p.K == 640 && p.N % 128 == 0 && p.N / 128 <= 16;
   if (!k320 && !k640) return false;

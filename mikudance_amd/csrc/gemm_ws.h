@@ -16,7 +16,7 @@
 //       waves 0-3  compute : LDS fragment reads + v_mfma_f32_16x16x32_f16 (C^T = W.A^T, so a lane ends up with 4 consecutive
 //                            output columns of one row), fp32 results to an LDS staging tile (double buffered)
 //       waves 4-5  loaders : issue the DMA of tile t+NS-1 and wait (vmcnt counts only their own DMAs: in-order) for tile t+1
-//       waves 6-7  stores  : tile t-1: staging tile + bias (+ row-broadcast term) (+ residual, prefetched two tiles ahead)
+//       waves 6-7  stores  : tile t-1: staging tile + bias (+ row-broadcast term) (+ residual, prefetched four tiles ahead)
 //                            -> one rounding -> coalesced 16-byte global stores
 //     ONE s_barrier per 16-row tile hands the stages round.
 //   * a launch with G = N / group column groups runs G workgroups side by side on the same row stream inside one XCD, so
@@ -26,6 +26,12 @@
 // (K = 320: consecutive rows already shift by 8 slots) and r & 15 for 80 (K = 640): every ds_read_b128 of a 16-row x 32-k
 // fragment touches 16 distinct slots per lane group.
 #pragma once
+#ifndef WS_RES_DEPTH
+#define WS_RES_DEPTH 4
+#endif
+#ifndef WS_COMPUTE_PIECES
+#define WS_COMPUTE_PIECES -1   // DMA pieces per tile issued by each compute wave (-1: default split)
+#endif
 
 struct WsParams {
   const half_t* A;
@@ -53,12 +59,14 @@ struct WsCfg {
   static constexpr int CSTAGE = TR * CS_LD * 4;
   static constexpr int NS = (160 * 1024 - 2 * CSTAGE) / STAGE > 12 ? 12 : (160 * 1024 - 2 * CSTAGE) / STAGE;
   static constexpr int DPT = STAGE / 1024;        // DMA wave-instructions per tile
-  static constexpr int PER = DPT / 2;             // ... per loader wave
+  static constexpr int CP = WS_COMPUTE_PIECES < 0 ? (KS <= 10 ? 1 : 3) : WS_COMPUTE_PIECES;   // pieces per tile issued by each compute wave
+  static constexpr int PER = (DPT - 4 * CP) / 2;  // ... by each of the two loader waves
   static constexpr int SMEM = NS * STAGE + 2 * CSTAGE;
   static constexpr int CHUNKS = TR * GC / 8;      // 16-byte output pieces per tile
   static constexpr int SPL = CHUNKS / 128;        // ... per lane of the two store waves
-  static_assert(DPT % 2 == 0 && CHUNKS % 128 == 0, "tile must split evenly over the loader / store waves");
-  static_assert((NS - 2) * PER <= 63, "vmcnt immediate");
+  static constexpr int PD = KS <= 10 ? 3 : 6;     // A fragments in flight per compute wave (register budget: 256 per wave)
+  static_assert((DPT - 4 * CP) % 2 == 0 && CHUNKS % 128 == 0, "tile must split evenly over the loader / store waves");
+  static_assert((NS - 2) * PER <= 63 && (NS - 2) * CP <= 63, "vmcnt immediate");
 };
 
 template <int CPR>
@@ -66,7 +74,7 @@ __device__ __forceinline__ int ws_swz(int row) {
   return CPR == 40 ? ((row >> 1) & 7) : (row & 15);
 }
 
-template <int KS, int CB>
+template <int KS, int CB, bool RES, bool RA>
 __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   using Cfg = WsCfg<KS, CB>;
   constexpr int K = Cfg::K, CPR = Cfg::CPR, GC = Cfg::GC, TR = Cfg::TR, STAGE = Cfg::STAGE, NS = Cfg::NS, CS_LD = Cfg::CS_LD;
@@ -94,19 +102,72 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wf[cb][ks] = *reinterpret_cast<const half8_t*>(wp + (size_t)cb * 16 * K + 32 * ks);
     }
+    // Drain the weight loads HERE, with the builtin the compiler's waitcnt pass understands: left to itself it waits lazily at
+    // the first use of each fragment, i.e. it plants ~50 `s_waitcnt vmcnt(N)` between the MFMAs of the tile loop, and every
+    // extra issue slot between two MFMAs of a one-wave-per-SIMD stream costs far more than its own cycle (MI355X guide,
+    // "one EXTRA issue slot between two MFMAs": measured here as 38 instead of 17 cycles per MFMA).
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
     const int row = lane & 15, kq = lane >> 4;
     const int rbase = row * CPR, sw = ws_swz<CPR>(row);
+    // the compute waves also issue CP of each tile's DMA pieces (one wave can only issue a piece every few hundred cycles:
+    // two loader waves alone cap the tile rate); after the drain above their vmcnt counts nothing but these DMAs
+    constexpr int CP = Cfg::CP;
+    const half_t* cpp[CP > 0 ? CP : 1];
+    const size_t castep = (size_t)p.streams * TR * p.lda;
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      const int pidx = (2 * Cfg::PER + wave * CP + i) * 64 + lane;
+      const int r = pidx / CPR, c = pidx % CPR;
+      cpp[i] = p.A + (size_t)(stream * TR + r) * p.lda + ((c ^ ws_swz<CPR>(r)) << 3);
+    }
+    auto cissue = [&](int it) {                     // called with it = 0, 1, 2, ... in order
+      char* st = ring + (it % NS) * STAGE;
+#pragma unroll
+      for (int i = 0; i < CP; ++i) {
+        const int base = __builtin_amdgcn_readfirstlane((2 * Cfg::PER + wave * CP + i) * 64);
+        __builtin_amdgcn_global_load_lds((gptr_t)cpp[i], (lptr_t)(st + base * 16), 16, 0, 0);
+        cpp[i] += castep;
+      }
+    };
+    if constexpr (CP > 0) {
+      const int pre = my_tiles < NS - 1 ? my_tiles : NS - 1;
+      for (int it = 0; it < pre; ++it) cissue(it);
+    }
     for (int it = 0; it < my_tiles; ++it) {
+      if constexpr (CP > 0) {
+        if (it + NS - 2 < my_tiles) wait_vmcnt<(NS - 2) * CP>();
+        else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();                 // b_it: tile `it` has landed; staging buffer it & 1 is free
+      if constexpr (CP > 0) {
+        if (it + NS - 1 < my_tiles) cissue(it + NS - 1);
+      }
       const char* st = ring + (it % NS) * STAGE;
       floatx4 acc[CB];
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+      // one wave per SIMD issues the MFMAs, so nothing else hides the LDS latency of the A fragments: keep PD of them in
+      // flight (a rotating register buffer; ds_read results return in order, the compiler counts lgkmcnt)
+      constexpr int PD = Cfg::PD;
+      half8_t af[PD];
+      // slot (4ks + kq) ^ sw: the swizzle only touches the low SWB bits, so there are P = 2^SWB / 4 distinct per-lane base
+      // addresses per tile and every fragment read is base[ks % P] + a compile-time offset (no address VALU between MFMAs)
+      constexpr int SWB = CPR == 40 ? 3 : 4, P = (1 << SWB) / 4;
+      const char* fb[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) fb[j] = st + (rbase + ((4 * j + kq) ^ sw)) * 16;
+      auto frag = [&](int ks) { return *reinterpret_cast<const half8_t*>(fb[ks % P] + (ks / P) * (16 << SWB)); };
+#pragma unroll
+      for (int j = 0; j < PD; ++j) af[j] = frag(j);
+      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);                         // PD ds_reads first ...
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const half8_t af = *reinterpret_cast<const half8_t*>(st + (rbase + ((4 * ks + kq) ^ sw)) * 16);
+        const half8_t cur = af[ks % PD];
+        if (ks + PD < KS) af[ks % PD] = frag(ks + PD);
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb][ks], af, acc[cb], 0, 0, 0);
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb][ks], cur, acc[cb], 0, 0, 0);
+        if (ks + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ... then one refill per k step, issued
+        __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                       //     ahead of that step's CB MFMAs
       }
       // acc[cb][r] = C[m = row][n = wave*16CB + cb*16 + 4*kq + r]
       float* cs = cst + (it & 1) * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
@@ -116,18 +177,24 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     __builtin_amdgcn_s_barrier();                   // b_{my_tiles}: the last staging tile is complete
   } else if (wave < 6) {
     // ------------------------------------------------------------------------------------------------ loader waves
+    // per-lane source pointers are tile invariant up to a constant stride (M % 16 == 0 is a launch precondition, so no row
+    // clamp): one DMA piece per tile costs its issue slot plus a 64-bit pointer bump, nothing else
     const int lw = wave - 4;
-    auto issue = [&](int it) {
-      const int m0 = (stream + it * p.streams) * TR;
+    const half_t* sp[Cfg::PER];
+    const size_t astep = (size_t)p.streams * TR * p.lda;
+#pragma unroll
+    for (int i = 0; i < Cfg::PER; ++i) {
+      const int pidx = (lw * Cfg::PER + i) * 64 + lane;
+      const int r = pidx / CPR, c = pidx % CPR;
+      sp[i] = p.A + (size_t)(stream * TR + r) * p.lda + ((c ^ ws_swz<CPR>(r)) << 3);
+    }
+    auto issue = [&](int it) {                      // called with it = 0, 1, 2, ... in order
       char* st = ring + (it % NS) * STAGE;
 #pragma unroll
       for (int i = 0; i < Cfg::PER; ++i) {
         const int base = __builtin_amdgcn_readfirstlane((lw * Cfg::PER + i) * 64);   // first 16-byte slot of this instruction
-        const int pidx = base + lane;
-        const int r = pidx / CPR, c = pidx % CPR;
-        const int gr = min(m0 + r, p.M - 1);
-        const half_t* src = p.A + (size_t)gr * p.lda + ((c ^ ws_swz<CPR>(r)) << 3);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + base * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)sp[i], (lptr_t)(st + base * 16), 16, 0, 0);
+        sp[i] += astep;
       }
     };
     const int pre = my_tiles < NS - 1 ? my_tiles : NS - 1;
@@ -142,69 +209,123 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     __builtin_amdgcn_s_barrier();                   // b_{my_tiles}
   } else {
     // ------------------------------------------------------------------------------------------------ store waves
+    // Lean on purpose: two waves move every output byte of the workgroup, so per 16-byte piece the loop is 2 LDS reads,
+    // 8 fp32 adds per epilogue term, 4 packed converts, a 64-bit pointer bump and the store.  Pointers advance by a constant
+    // per tile; bias / row-broadcast terms live in registers as floats; only the last tile of a stream can be ragged.
     const int sid = (wave - 6) * 64 + lane;         // 0..127
     constexpr int CPRO = GC / 8;                    // 16-byte pieces per output row
-    int prow[Cfg::SPL], pcol[Cfg::SPL];
-    half8_t bias[Cfg::SPL];
+    constexpr int SPL = Cfg::SPL;
+    int prow[SPL], pcol[SPL];
+    float biasf[SPL][8];
+    half_t* cp[SPL];
+    const half_t* rp[SPL];
+    const size_t cstep = (size_t)p.streams * TR * p.ldc, rstep = (size_t)p.streams * TR * p.ldr;
 #pragma unroll
-    for (int i = 0; i < Cfg::SPL; ++i) {
+    for (int i = 0; i < SPL; ++i) {
       const int id = i * 128 + sid;
       prow[i] = id / CPRO;
       pcol[i] = (id % CPRO) * 8;
-      bias[i] = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pcol[i]) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const half8_t bv = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pcol[i]) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) biasf[i][j] = (float)bv[j];
+      cp[i] = p.C + (size_t)(stream * TR + prow[i]) * p.ldc + n0 + pcol[i];
+      rp[i] = RES ? p.residual + (size_t)(stream * TR + prow[i]) * p.ldr + n0 + pcol[i] : nullptr;
     }
-    half8_t res[2][Cfg::SPL];
-    auto fetch_res = [&](int it, half8_t (&dst)[Cfg::SPL]) {
+    constexpr int RD = RA ? 2 : WS_RES_DEPTH;       // residual tiles in flight per store wave (fewer when the row-broadcast term
+                                                    // also lives in registers: 256 VGPRs per wave)
+    half8_t res[RES ? RD : 1][SPL];
+    auto fetch_res = [&](int it, half8_t (&dst)[SPL]) {          // tile `it` of this stream; rp[] points at tile `it`
       const int m0 = (stream + it * p.streams) * TR;
 #pragma unroll
-      for (int i = 0; i < Cfg::SPL; ++i) {
-        const int m = min(m0 + prow[i], p.M - 1);
-        dst[i] = *reinterpret_cast<const half8_t*>(p.residual + (size_t)m * p.ldr + n0 + pcol[i]);
+      for (int i = 0; i < SPL; ++i) {
+        const half_t* q = (m0 + prow[i] < p.M) ? rp[i] : p.residual;      // ragged last tile: any valid address
+        dst[i] = *reinterpret_cast<const half8_t*>(q);
+        rp[i] += rstep;
       }
     };
-    auto store_tile = [&](int it, const half8_t (&rs)[Cfg::SPL]) {
+    int cur_group = -1;
+    float raf[RA ? SPL : 1][8];
+    auto store_tile = [&](int it, const half8_t (&rs)[SPL]) {
       const int m0 = (stream + it * p.streams) * TR;
       const float* cs = cst + (it & 1) * (TR * CS_LD);
+      const bool full = m0 + TR <= p.M;
+      if constexpr (RA) {
+        // row-broadcast term: one table row per `rows_per_group` output rows (a frame); reloaded when the tile enters a new
+        // group.  Tiles that straddle two groups take the per-piece path.
+        const int g0 = m0 / p.rows_per_group, g1 = min(m0 + TR - 1, p.M - 1) / p.rows_per_group;
+        if (g0 != cur_group || g1 != g0) {
 #pragma unroll
-      for (int i = 0; i < Cfg::SPL; ++i) {
-        const int m = m0 + prow[i];
-        const floatx4 a = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i]);
-        const floatx4 b = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i] + 4);
-        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+          for (int i = 0; i < SPL; ++i) {
+            const int g = g1 == g0 ? g0 : min(m0 + prow[i], p.M - 1) / p.rows_per_group;
+            const half8_t ra = *reinterpret_cast<const half8_t*>(p.rowadd + (size_t)g * p.ldra + n0 + pcol[i]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)bias[i][j];
-        if (p.rowadd && m < p.M) {
-          const half8_t ra = *reinterpret_cast<const half8_t*>(p.rowadd + (size_t)(m / p.rows_per_group) * p.ldra + n0 + pcol[i]);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)ra[j];
+            for (int j = 0; j < 8; ++j) raf[i][j] = (float)ra[j];
+          }
+          cur_group = g1 == g0 ? g0 : -1;
         }
-        if (p.residual) {
+      }
+      // all LDS reads first (one latency per tile, not one per piece), then the arithmetic; the ragged-tile predicate is
+      // a uniform branch around two copies of the loop, so the common path has no per-piece exec masking
+      floatx4 ca[SPL], cb2[SPL];
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        ca[i] = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i]);
+        cb2[i] = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i] + 4);
+      }
+      auto piece = [&](int i) {
+        float v[8] = {ca[i][0], ca[i][1], ca[i][2], ca[i][3], cb2[i][0], cb2[i][1], cb2[i][2], cb2[i][3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += biasf[i][j];
+        if constexpr (RA) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += raf[i][j];
+        }
+        if constexpr (RES) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += (float)rs[i][j];
         }
         half8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-        if (m < p.M) *reinterpret_cast<half8_t*>(p.C + (size_t)m * p.ldc + n0 + pcol[i]) = o;
+        return o;
+      };
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          *reinterpret_cast<half8_t*>(cp[i]) = piece(i);
+          cp[i] += cstep;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          const half8_t o = piece(i);
+          if (m0 + prow[i] < p.M) *reinterpret_cast<half8_t*>(cp[i]) = o;
+          cp[i] += cstep;
+        }
       }
     };
-    if (p.residual) {
-      fetch_res(0, res[0]);
-      if (my_tiles > 1) fetch_res(1, res[1]);
+    if constexpr (RES) {
+#pragma unroll
+      for (int j = 0; j < RD; ++j)
+        if (j < my_tiles) fetch_res(j, res[j]);
     }
     // barrier b_it (it = 0 .. my_tiles): afterwards the compute waves work on tile it and this wave stores tile it-1, then
-    // prefetches the residual of tile it+1 (two tile periods ahead).  Unrolled by two so that the two residual buffers are
-    // addressed statically: even tiles use res[0], odd tiles res[1].
-    for (int it = 0; it <= my_tiles; it += 2) {
-      __builtin_amdgcn_s_barrier();                                   // b_it
-      if (it >= 1) {
-        store_tile(it - 1, res[1]);
-        if (p.residual && it + 1 < my_tiles) fetch_res(it + 1, res[1]);
+    // prefetches the residual of tile it-1+RD into the buffer it has just freed (RD tile periods ahead: the HBM latency
+    // under load is several tile periods).  Unrolled by RD so that the residual buffers are addressed statically.
+    for (int base = 0; base <= my_tiles; base += RD) {
+#pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        const int it = base + j;
+        if (it <= my_tiles) {
+          __builtin_amdgcn_s_barrier();                               // b_it
+          if (it >= 1) {
+            store_tile(it - 1, res[RES ? (j + RD - 1) % RD : 0]);
+            if constexpr (RES) {
+              if (it - 1 + RD < my_tiles) fetch_res(it - 1 + RD, res[(j + RD - 1) % RD]);
+            }
+          }
+        }
       }
-      if (it + 1 > my_tiles) break;
-      __builtin_amdgcn_s_barrier();                                   // b_{it+1}
-      store_tile(it, res[0]);
-      if (p.residual && it + 2 < my_tiles) fetch_res(it + 2, res[0]);
     }
   }
 }

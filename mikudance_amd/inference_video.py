@@ -1,0 +1,128 @@
+"""`python -m mikudance_amd.inference_video --config configs/inference/inference_video.yaml [-W 768 -H 768 --steps 30 ...]`
+
+Drop-in for the reference's scripts/inference_video.py (its `main`, :61-234) with every module served by this package: same
+command line, same YAML keys, same call order, same output file naming.  Nothing third party is needed beyond what this image
+has (no omegaconf / diffusers / PyAV / cv2 / torchvision / scikit-image): see mikudance_amd/io_utils.py for the adapters.
+
+    vae            = AutoencoderKL.from_pretrained(config.pretrained_vae_path)                     (:76-79)
+    unet           = UNet2DConditionModel.from_pretrained(base, subfolder="unet")                  (:81-84)  -> UNet2DConditionModelPlain
+    reference_unet = UNet2DConditionModel_MIX.from_unet(unet)                                      (:85)
+    denoising_unet = UNet3DConditionModel.from_pretrained_2d(base, motion_module_path, subfolder="unet",
+                                                             unet_additional_kwargs=infer_config.unet_additional_kwargs)  (:90-95)
+    image_enc      = CLIPVisionModelWithProjection.from_pretrained(config.image_encoder_path)      (:97-99)
+    scheduler      = DDIMScheduler(**infer_config.noise_scheduler_kwargs)                          (:101-102)
+    *.load_state_dict(torch.load(...))                                                             (:111-117)
+    pipe(ref_image, ref_skel, pose, face, hand, scene_motion, W, H, F, steps, cfg, generator)      (:211-224)
+    save_videos_grid(cat([ref, pose, video]), ".../{skel}_{ref}_{H}x{W}_{cfg}_{time}.mp4", n_rows=3, fps)     (:228-234)
+
+`--video_decoder` (AutoencoderKLTemporalDecoder) is not implemented here and says so."""
+import argparse
+import os
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import (AutoencoderKL, CLIPVisionModelWithProjection, DDIMScheduler, MikuDanceVideoPipeline, UNet2DConditionModel,
+               UNet2DConditionModelPlain, UNet3DConditionModel)
+from .io_utils import frames_to_tensor, get_fps, load_config, read_frames, resize_depth, save_videos_grid, to_container
+from .scene_motion import camera_to_scene_motion
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config")
+    parser.add_argument("-W", type=int, default=768)
+    parser.add_argument("-H", type=int, default=768)
+    parser.add_argument("--seed", type=int, default=100)
+    parser.add_argument("--cfg", type=float, default=3.5)
+    parser.add_argument("--steps", type=int, default=30)
+    parser.add_argument("--fps", type=int)
+    parser.add_argument("--video_decoder", action="store_true",
+                        help="The temporal decoder produces less noise in the results but leads to longer inference times.")
+    parser.add_argument("--output_dir", default="output", help="(addition) root of the dated output tree")
+    return parser.parse_args(argv)
+
+
+def _none(v):
+    return v is None or v == "None"
+
+
+def build_pipeline(config, infer_config, weight_dtype, device="cuda", video_decoder=False):
+    """scripts/inference_video.py:72-130."""
+    if video_decoder:
+        raise NotImplementedError("--video_decoder (AutoencoderKLTemporalDecoder) is not implemented on the MI355X path; "
+                                  "the default per-frame AutoencoderKL decode is")
+    vae = AutoencoderKL.from_pretrained(config.pretrained_vae_path).to(device, dtype=weight_dtype)
+    unet = UNet2DConditionModelPlain.from_pretrained(config.pretrained_base_model_path, subfolder="unet")
+    reference_unet = UNet2DConditionModel.from_unet(unet)
+    del unet
+    denoising_unet = UNet3DConditionModel.from_pretrained_2d(
+        config.pretrained_base_model_path, config.motion_module_path, subfolder="unet",
+        unet_additional_kwargs=infer_config.unet_additional_kwargs).to(dtype=weight_dtype, device=device)
+    image_enc = CLIPVisionModelWithProjection.from_pretrained(config.image_encoder_path).to(dtype=weight_dtype, device=device)
+    scheduler = DDIMScheduler(**to_container(infer_config.noise_scheduler_kwargs))
+    denoising_unet.load_state_dict(torch.load(config.denoising_unet_path, map_location="cpu", weights_only=True), strict=False)
+    reference_unet.load_state_dict(torch.load(config.reference_unet_path, map_location="cpu", weights_only=True))
+    denoising_unet.eval()
+    reference_unet.eval()
+    pipe = MikuDanceVideoPipeline(vae=vae, image_encoder=image_enc, reference_unet=reference_unet, denoising_unet=denoising_unet,
+                                  scheduler=scheduler, video_decoder=video_decoder)
+    return pipe.to(device, dtype=weight_dtype)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config = load_config(args.config)
+    weight_dtype = torch.float16 if config.weight_dtype == "fp16" else torch.float32
+    if weight_dtype != torch.float16:
+        raise NotImplementedError("the MI355X kernels compute in fp16 (weight_dtype: 'fp16', the reference's shipped setting)")
+    infer_config = load_config(config.inference_config)
+    generator = torch.manual_seed(args.seed)
+    width, height = args.W, args.H
+    assert width % 8 == 0 and height % 8 == 0      # the vae works at 1/8 resolution (scripts/inference_video.py:108)
+    pipe = build_pipeline(config, infer_config, weight_dtype, video_decoder=args.video_decoder)
+
+    date_str = datetime.now().strftime("%Y%m%d")
+    time_str = datetime.now().strftime("%H%M%S")
+    save_dir = Path(f"{args.output_dir}/{date_str}/{time_str}--seed_{args.seed}-{args.W}x{args.H}")
+    save_dir.mkdir(exist_ok=True, parents=True)
+
+    if _none(config.tgt_pose_path):
+        raise ValueError("Target pose is required!")
+    pose_pils = read_frames(config.tgt_pose_path)
+    src_fps = get_fps(config.tgt_pose_path)
+    num_frames = len(pose_pils)
+    black = lambda: [Image.new("RGB", pose_pils[0].size, (0, 0, 0)) for _ in range(num_frames)]
+    face_pils = black() if _none(config.get("tgt_face_path")) else read_frames(config.tgt_face_path)
+    hand_pils = black() if _none(config.get("tgt_hand_path")) else read_frames(config.tgt_hand_path)
+    if _none(config.get("tgt_w2c_path")) or _none(config.get("tgt_c2w_path")):
+        w2c_npy = np.eye(4).reshape((1, 4, 4)).repeat(num_frames, axis=0)
+        c2w_npy = np.eye(4).reshape((1, 4, 4)).repeat(num_frames, axis=0)
+    else:
+        w2c_npy, c2w_npy = np.load(config.tgt_w2c_path), np.load(config.tgt_c2w_path)
+    depth_map = np.zeros((1, height, width)) if _none(config.get("ref_depth_path")) else np.load(config.ref_depth_path)
+    depth_map = resize_depth(depth_map, (1, height // 8, width // 8))
+    scene_motion_npy = camera_to_scene_motion([w2c_npy[k] for k in range(w2c_npy.shape[0])], [c2w_npy[k] for k in range(c2w_npy.shape[0])],
+                                              [3.2, 3.2, 1.6, 1.6], depth_map, width // 8, height // 8, False)
+    print("Total frames: {}".format(num_frames))
+
+    skel_name = os.path.splitext(os.path.basename(config.tgt_pose_path))[0]
+    ref_name = os.path.splitext(os.path.basename(config.ref_image_path))[0]
+    pose_tensor = frames_to_tensor(pose_pils, height, width)
+    ref_image_pil = Image.open(config.ref_image_path).convert("RGB")
+    ref_skel_pil = Image.open(config.ref_skel_path).convert("RGB")
+    ref_image_tensor = frames_to_tensor([ref_image_pil], height, width).repeat(1, 1, num_frames, 1, 1)
+
+    out = pipe(ref_image_pil, ref_skel_pil, pose_pils, face_pils, hand_pils, scene_motion_npy, width, height, num_frames,
+               args.steps, args.cfg, generator=generator)
+    video = torch.cat([ref_image_tensor, pose_tensor, out.videos], dim=0)
+    path = f"{save_dir}/{skel_name}_{ref_name}_{args.H}x{args.W}_{int(args.cfg)}_{time_str}.mp4"
+    save_videos_grid(video, path, n_rows=3, fps=src_fps if args.fps is None else args.fps)
+    return path
+
+
+if __name__ == "__main__":
+    main()

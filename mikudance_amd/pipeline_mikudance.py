@@ -27,6 +27,36 @@ from .context import get_context_scheduler
 from .mutual_mix_attention import ReferenceAttentionControl
 
 
+# ---- latent interpolation helpers: API mirror of reference src/pipelines/utils.py (a module-level method switch that the
+# caller sets; nothing in the reference sets it, so interpolation_factor >= 2 without it fails there exactly like here)
+tensor_interpolation = None
+
+
+def get_tensor_interpolation_method():
+    return tensor_interpolation
+
+
+def set_tensor_interpolation_method(is_slerp):
+    global tensor_interpolation
+    tensor_interpolation = slerp if is_slerp else linear
+
+
+def linear(v1, v2, t):
+    return (1.0 - t) * v1 + t * v2
+
+
+def slerp(v0, v1, t, DOT_THRESHOLD=0.9995):
+    """Spherical interpolation of two latent frames treated as single vectors (src/pipelines/utils.py:20-31); falls back to
+    the straight line when they are nearly parallel."""
+    u0 = v0 / v0.norm()
+    u1 = v1 / v1.norm()
+    dot = (u0 * u1).sum()
+    if dot.abs() > DOT_THRESHOLD:
+        return (1.0 - t) * v0 + t * v1
+    omega = dot.acos()
+    return (((1.0 - t) * omega).sin() * v0 + (t * omega).sin() * v1) / omega.sin()
+
+
 @dataclass
 class MikuDanceVideoPipelineOutput:
     videos: Union[torch.Tensor, np.ndarray]
@@ -229,6 +259,30 @@ class MikuDanceVideoPipeline:
         video = (video / 2 + 0.5).clamp(0, 1)
         return video.cpu().float().numpy()
 
+    def interpolate_latents(self, latents, interpolation_factor, device):
+        """reference :317-360 -- (F - 1) * factor + 1 frames: every original frame, and factor - 1 blends between neighbours
+        (method chosen with set_tensor_interpolation_method; a few elementwise ops on 1 MB of latents, once per clip)."""
+        if interpolation_factor < 2:
+            return latents
+        method = get_tensor_interpolation_method()
+        if method is None:
+            raise TypeError("interpolate_latents: call set_tensor_interpolation_method(is_slerp) first (the reference's module-level "
+                            "`tensor_interpolation` is None until then, src/pipelines/utils.py:3-12)")
+        b, c, f, h, w = latents.shape
+        out = torch.zeros((b, c, (f - 1) * interpolation_factor + 1, h, w), device=latents.device, dtype=latents.dtype)
+        rate = [i / interpolation_factor for i in range(interpolation_factor)][1:]
+        idx = 0
+        v1 = None
+        for i0 in range(f - 1):
+            v0, v1 = latents[:, :, i0], latents[:, :, i0 + 1]
+            out[:, :, idx] = v0
+            idx += 1
+            for r in rate:
+                out[:, :, idx] = method(v0.to(device=device), v1.to(device=device), r).to(latents.device)
+                idx += 1
+        out[:, :, idx] = v1
+        return out
+
     def clip_embeds(self, ref_image):
         """reference :406-416 -- all 257 tokens: last_hidden_state -> post_layernorm -> visual_projection.
         `image_encoder` is mikudance_amd.CLIPVisionModelWithProjection (HIP kernels) or any module with the transformers
@@ -250,9 +304,9 @@ class MikuDanceVideoPipeline:
                  return_dict: bool = True, callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
                  callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=None, context_stride=1,
                  context_overlap=8, context_batch_size=1, interpolation_factor=1, **kwargs):
-        if eta != 0.0 or context_batch_size != 1 or interpolation_factor != 1:
-            raise NotImplementedError("eta != 0, context_batch_size != 1 and interpolation_factor != 1 are never used by "
-                                      "scripts/inference_video.py (SURVEY.md component 3b)")
+        if eta != 0.0 or context_batch_size != 1:
+            raise NotImplementedError("eta != 0 and context_batch_size != 1 are never used by scripts/inference_video.py "
+                                      "(SURVEY.md component 3b)")
         height = height or 768
         width = width or 768
         device = self._execution_device
@@ -273,6 +327,8 @@ class MikuDanceVideoPipeline:
         ref_latents = torch.cat([ref_image_latents, pose_ref_latents, pose_tgt, face_tgt, hand_tgt, tracker], dim=1)[None]
         latents = self.denoise(latents, ref_latents, image_prompt_embeds, num_inference_steps, guidance_scale, context_schedule,
                                context_frames, context_stride, context_overlap, callback, callback_steps)
+        if interpolation_factor > 0:
+            latents = self.interpolate_latents(latents, interpolation_factor, device)
         images = self.decode_temporal(latents) if self.video_decoder else self.decode_latents(latents)
         if output_type == "tensor":
             images = torch.from_numpy(images)

@@ -305,6 +305,35 @@ def g11_clip():
     json.dump(meta, open(os.path.join(OUT, "g11_meta.json"), "w"))
 
 
+def g12_interpolation():
+    """src/pipelines/utils.py linear / slerp (TRUE reference, imported) on seeded latent frames, incl. the near-parallel
+    fallback, plus interpolate_latents' frame layout restated line by line from src/pipelines/pipeline_mikudance.py:317-360
+    (that file cannot be imported here) around the reference's own blend functions."""
+    from src.pipelines import utils as RU
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 4, 4, 6, 5, generator=g)
+    t = {"g12.latents": lat}
+    for name, is_slerp in (("linear", False), ("slerp", True)):
+        RU.set_tensor_interpolation_method(is_slerp)
+        for factor in (2, 3):
+            new = torch.zeros(1, 4, (lat.shape[2] - 1) * factor + 1, 6, 5)
+            rate = [i / factor for i in range(factor)][1:]
+            idx = 0
+            for i0, i1 in zip(range(lat.shape[2]), range(lat.shape[2])[1:]):
+                v0, v1 = lat[:, :, i0], lat[:, :, i1]
+                new[:, :, idx] = v0
+                idx += 1
+                for f in rate:
+                    new[:, :, idx] = RU.get_tensor_interpolation_method()(v0, v1, f)
+                    idx += 1
+            new[:, :, idx] = v1
+            t[f"g12.{name}.x{factor}"] = new
+    v = torch.randn(4, 6, 5, generator=g)
+    t["g12.slerp_parallel"] = RU.slerp(v, v * 1.0001 + 1e-5, 0.3)
+    t["g12.slerp_parallel_in"] = v
+    save_file({k: x.contiguous() for k, x in t.items()}, os.path.join(OUT, "g12_interpolation.safetensors"))
+
+
 def g6_keys():
     ref, den, _, _ = build_unets()      # full SD-1.5 geometry (constructor defaults + cross_attention_dim 768)
     json.dump({"denoising_unet": {k: list(v.shape) for k, v in den.state_dict().items()},
@@ -324,7 +353,7 @@ def g7_ddim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which: g1_windows()
     if "g2" in which: g2_scene_motion()
     if "g3" in which: g3_blocks()
@@ -335,5 +364,6 @@ if __name__ == "__main__":
     if "g9" in which: g9_fullsize()
     if "g10" in which: g10_odd_and_plain_gn()
     if "g11" in which: g11_clip()
+    if "g12" in which: g12_interpolation()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

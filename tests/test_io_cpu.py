@@ -204,3 +204,25 @@ def test_guidance_tensor_assembly_values(golden_dir):
     want_noise = torch.randn((1, 4, F_, H // 8, W // 8), generator=torch.manual_seed(7))
     assert torch.equal(seen["latents"].float(), want_noise)
     assert tuple(out.videos.shape) == (1, 3, F_, H, W) and out.videos.dtype == torch.float32
+
+
+def test_interpolate_latents_vs_reference_golden(golden_dir):
+    """interpolate_latents / linear / slerp against goldens built from the reference's own src/pipelines/utils.py."""
+    from safetensors.torch import load_file
+    from mikudance_amd import pipeline_mikudance as P
+    g = load_file(os.path.join(golden_dir, "g12_interpolation.safetensors"))
+    pipe = M.MikuDanceVideoPipeline(None, None, None, None, M.DDIMScheduler(**SCHED_KWARGS))
+    lat = g["g12.latents"]
+    assert pipe.interpolate_latents(lat, 1, "cpu") is lat
+    P.tensor_interpolation = None
+    with pytest.raises(TypeError):
+        pipe.interpolate_latents(lat, 2, "cpu")
+    for name, is_slerp in (("linear", False), ("slerp", True)):
+        P.set_tensor_interpolation_method(is_slerp)
+        for factor in (2, 3):
+            got = pipe.interpolate_latents(lat, factor, "cpu")
+            want = g[f"g12.{name}.x{factor}"]
+            assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6), (name, factor)
+    v = g["g12.slerp_parallel_in"]
+    assert torch.allclose(P.slerp(v, v * 1.0001 + 1e-5, 0.3), g["g12.slerp_parallel"], atol=1e-6)
+    P.tensor_interpolation = None

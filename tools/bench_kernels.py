@@ -39,6 +39,16 @@ def main(which):
             o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
             ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=res, act=ops.ACT_GEGLU if geglu else 0, out=o))
             out[f"gemm {M}x{N}x{K}{' geglu' if geglu else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9)
+    if "skinny" in which:      # the HBM-bound short-K projections (W-stationary streaming kernel candidates), with their epilogues
+        for M, N, K, res in [(294912, 320, 320, False), (294912, 320, 320, True), (294912, 960, 320, False), (294912, 640, 320, False),
+                             (147456, 320, 320, True), (73728, 640, 640, False), (73728, 640, 640, True), (73728, 1920, 640, False),
+                             (73728, 1280, 640, False), (294912, 320, 640, True)]:
+            a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+            r = rnd(M, N) if res else None
+            o = torch.empty((M, N), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=r, out=o))
+            byts = 2.0 * (M * K + M * N * (2 if res else 1))
+            out[f"gemm {M}x{N}x{K}{' +res' if res else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9, byts / ms / 1e6)
     if "small" in which:       # the 12x12 level (M = 4608): fewer workgroups than CU slots
         for M, N, K, geglu in [(4608, 1280, 1280, False), (4608, 10240, 1280, True), (4608, 1280, 5120, False), (4608, 2560, 1280, False)]:
             a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
@@ -81,8 +91,10 @@ def main(which):
             x2 = x.view(-1, C)
             ms = timeit(lambda: ops.layernorm(x2, g, b))
             out[f"layernorm {B * HW}x{C}"] = (ms, 4.0 * B * HW * C / ms / 1e6)
-    for k, (ms, rate) in out.items():
-        print(f"{k:44s} {ms:9.3f} ms  {rate:10.1f} {'GB/s' if k.startswith(('temporal', 'groupnorm', 'layernorm')) else 'TFLOP/s'}")
+    for k, v in out.items():
+        ms, rate = v[0], v[1]
+        extra = f"  {v[2]:8.1f} GB/s (A + C{' + R' if '+res' in k else ''})" if len(v) > 2 else ""
+        print(f"{k:44s} {ms:9.3f} ms  {rate:10.1f} {'GB/s' if k.startswith(('temporal', 'groupnorm', 'layernorm')) else 'TFLOP/s'}{extra}")
 
 
 if __name__ == "__main__":
