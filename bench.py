@@ -16,7 +16,8 @@ Extra objects on the JSON line:
                pass of the same clip run right after the timed region (instrumenting ~17k launches per clip inside the timed
                region would add its own launch gaps to `value`; both times are reported)
   cpu_baseline the CPU oracle (a port of the reference's PyTorch path, oracle/cpu_ref.py) timed on this host's cores on a
-               bounded sample: ONE DDIM step of ONE frame at 768x768 with the full-width UNets, literal reference algorithm
+               bounded sample after a warm-up: configs[0] in full (4 steps) and ONE DDIM step of 2 frames at 768x768 with the
+               full-width UNets, literal reference algorithm
 """
 import argparse
 import json
@@ -152,6 +153,11 @@ def main():
         roofline["traffic"] = rec["hbm_bytes_corrected"] if rec else None   # HBM-side bytes per launch (profiles/pmc_traffic.json)
         if rec:
             roofline["algorithmic_bytes"] = rec["algorithmic_bytes"]
+            # `traffic` is NOT measured by this run: it is copied from the builder's rocprofv3 --pmc passes over the same kernel
+            # and shape (PMC counters cannot be collected inside a timed benchmark); source file and date travel with it
+            roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "collected": rec.get("collected", "round 1"),
+                                          "method": rec.get("method", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                                                      "FETCH_SIZE x2 (gfx950 correction, MI355X guide HBM section)")}
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     frames_total = args.frames * args.steps * world
@@ -169,14 +175,18 @@ def main():
                    "(N(0,1/fan_in), seeds 1234/4321)", "width": "reduced(debug)" if args.small else "full"},
         "executed_tflop_per_clip": total_flops / 1e12, "mfma_frac_whole_loop": total_flops / (elapsed / args.steps) / PEAK_MFMA_F16,
         "peak_hbm_gb": peak_gb, "kernel_ms_per_clip": kernel_ms, "instrumented_ms_per_step": inst_elapsed / inst_steps * 1e3, "setup_s": setup_s,
-        "kernel_families": {k: dict(ms_per_clip=v["ms"] / inst_steps, tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
-                                    gbps=(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if not v["flops"] else None,
+        # tflops for the contraction kernels; gbps = algorithmic bytes (inputs + outputs once) / time for every family: it is THE
+        # figure for the HBM-class ones (norms, temporal attention whose f x f core is 4 bytes per 2 f MACs, the skinny GEMMs)
+        "kernel_families": {k: dict(ms_per_clip=v["ms"] / inst_steps,
+                                    tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] and k != "temporal_attention" else None,
+                                    gbps=v["bytes"] / (v["ms"] * 1e-3) / 1e9,
                                     launches=v["count"] // inst_steps) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
         "roofline": roofline,
     }
-    top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]
     line["top_launch_shapes"] = [dict(label=k, ms_per_clip=v["ms"] / inst_steps, launches=v["count"] // inst_steps,
-                                      tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None) for k, v in top]
+                                      tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                                      gbps=v["bytes"] / (v["ms"] * 1e-3) / 1e9) for k, v in top]
     if os.environ.get("MD_BENCH_DUMP"):
         with open(os.environ["MD_BENCH_DUMP"], "w") as fh:
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
@@ -210,23 +220,39 @@ def full_guidance(ref_latents, frames, h, w):
 
 
 def cpu_baseline(ref_sd, den_sd, args, ctx):
-    """The CPU oracle (port of the reference's PyTorch path) on a bounded sample: ONE DDIM step of ONE frame at the
-    benchmark resolution, literal reference algorithm (reference UNet on [uncond|cond] + denoising UNet on [uncond|cond])."""
+    """The CPU oracle (a port of the reference's PyTorch path: the same ATen ops, fp32) on this host's cores, on a bounded
+    sample, after one untimed warm-up pass (thread pool, allocator, oneDNN primitive caches):
+      (1) BASELINE configs[0] IN FULL: 256x256 (32x32 latents), 4 frames, 4 DDIM steps, CFG, literal reference algorithm;
+      (2) ONE DDIM step at the benchmark resolution on f = 2 frames (reference_unet + denoising_unet on the [uncond | cond]
+          pair with temporal attention over the 2 frames) -- `value` = 2 frames / (ddim_steps x that time), i.e. the step
+          time extrapolated linearly over the steps; a full 16-frame clip is ~2 PFLOP = hours of CPU.
+    `cores` = torch's intra-op threads actually used; the physical core count of the host is reported beside it."""
     from oracle import cpu_ref as O                                     # cpu_baseline leg only
     from mikudance_amd.synth import synth_inputs
-    h = w = args.size // 8
-    lat, rl, emb = synth_inputs(1, h, w, ctx_len=ctx[0], ctx_dim=ctx[1], seed=100)
-    cores = torch.get_num_threads()
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:
+        physical = None
+    threads = torch.get_num_threads()
+    full_ctx = (257, 768) if not args.small else ctx
     with torch.no_grad():
+        lat1, rl1, emb1 = synth_inputs(4, 32, 32, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100)
+        O.denoise_loop(ref_sd, den_sd, lat1, rl1, emb1, 1, guidance_scale=args.guidance)          # warm-up (untimed)
         t0 = time.perf_counter()
-        g = rl[:, [0]].repeat(2, 1, 1, 1, 1).reshape(2, 22, h, w)
-        banks, _ = O.reference_unet_forward(ref_sd, g, emb.repeat((1, 1, 1)))
-        banks = {k: v.half().float() for k, v in banks.items()}
-        O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(999), emb, banks, cfg=True)
-        dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt * args.ddim_steps), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 DDIM step of 1 frame at {args.size}x{args.size} (reference_unet + denoising_unet, CFG pair, fp32, "
-                      f"full-width random-init weights) = {dt:.1f} s; frames/s = 1 / ({args.ddim_steps} steps x that)"}
+        O.denoise_loop(ref_sd, den_sd, lat1, rl1, emb1, 4, guidance_scale=args.guidance)
+        dt1 = time.perf_counter() - t0
+        h = w = args.size // 8
+        f = 2
+        lat, rl, emb = synth_inputs(f, h, w, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100)
+        t0 = time.perf_counter()
+        O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
+        dt2 = time.perf_counter() - t0
+    return {"value": f / (dt2 * args.ddim_steps), "unit": "frames/s", "cores": threads, "physical_cores": physical, "kind": "port",
+            "config1_full_s": dt1, "config1_frames_per_s": 4.0 / dt1,
+            "sample": f"after one warm-up pass: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) = {dt1:.1f} s; "
+                      f"(2) 1 DDIM step of {f} frames at {args.size}x{args.size} (reference_unet + denoising_unet, CFG pair, fp32, full-width "
+                      f"random-init weights) = {dt2:.1f} s; value = {f} frames / ({args.ddim_steps} steps x {dt2:.1f} s)"}
 
 
 if __name__ == "__main__":

@@ -9,8 +9,18 @@
  * allocated, freed or retained; kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call
  * returns immediately.  Activations are fp16, token-major / NHWC: a (B,H,W,C) image batch IS the row-major matrix
  * [B*H*W][C].  Weights are fp16 [N][K] with K contiguous (nn.Linear layout; 3x3 conv weights as
- * [Cout][ky][kx][Cin]).  Return value: 0 on success, negative on error (md_last_error() has the message);
- * thread-safe for distinct streams.
+ * [Cout][ky][kx][Cin]).  Return value: 0 on success, negative on error (md_last_error() has the message, per thread).
+ *
+ * Threading / devices: entry points may be called concurrently from several host threads on distinct streams, and one
+ * process may drive several GPUs (hipSetDevice before the call): the library keeps no per-call state, its one-time kernel
+ * attribute setup (> 64 KiB dynamic LDS) is done per device behind an atomic mask, and the MD_* tuning knobs are read from
+ * the environment once per process (thread-safe initialisation).  Two calls on the SAME stream are ordered by the stream.
+ *
+ * Aliasing: outputs must not overlap inputs, with ONE exception that the callers rely on: `residual` may be exactly the
+ * output (same pointer, same pitch) of md_gemm_f16 / md_conv3x3*_nhwc_f16 -- every kernel flavour reads a residual element
+ * in the thread that later writes the same output element (or, in the streaming kernel, reads whole rows that no workgroup
+ * has written yet); a partially overlapping residual is rejected.  md_groupnorm_nhwc_f16 and md_softmax_rows_f16 may run in
+ * place (y == x).
  */
 #ifndef MDANCE_HIP_H
 #define MDANCE_HIP_H
@@ -23,6 +33,7 @@ extern "C" {
 #define MD_ACT_SILU 1
 #define MD_ACT_RELU 2
 #define MD_ACT_GEGLU 3 /* W rows packed as alternating blocks of 32 'h' rows and 32 'g' rows; C gets N/2 columns */
+#define MD_ACT_QUICKGELU 4 /* x * sigmoid(1.702 x): CLIP vision tower MLP (src/pipelines/pipeline_mikudance.py:406-416) */
 
 int md_version(void);
 const char* md_last_error(void);

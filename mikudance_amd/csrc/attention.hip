@@ -217,18 +217,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 template <int D>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
   // fast path: 16-byte aligned K / V^T key chunks (DMA granularity) and a readable pad up to the next multiple of 8 keys
-  static int force_v1 = -1;
-  if (force_v1 < 0) force_v1 = getenv("MD_ATTN_V1") ? 1 : 0;
+  static const int force_v1 = getenv("MD_ATTN_V1") ? 1 : 0;
   const bool fast = !force_v1 && p.ldvt % 8 == 0 && p.kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(p.Vt) & 15) == 0 &&
                     ((p.Lk + 7) & ~7) <= p.kv_stride;
   if (fast) return launch_attn2<D>(p, stream);
   constexpr int KS = (D + 15) / 16, DQ = KS * 16, DVT = (D + 31) / 32;
   constexpr int smem = 2 * (KT * (DQ + 8) * 2 + DVT * 32 * (KT + 4) * 2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  md_ensure_dynamic_lds<attn_kernel<D>>(smem);
   dim3 grid(cdiv(p.Lq, 128), p.H, p.B);
   hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), smem, stream, p);
   MD_CHECK_LAUNCH("md_attention_fwd");

@@ -386,11 +386,7 @@ static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
 #endif
   constexpr int DVT = (D + 31) / 32;
   constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128) + ((D % 16) == 8 ? 32 * D * 2 + 16 : 0);   // + the FOLD constants
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<D, NST, QT, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  md_ensure_dynamic_lds<attn2_kernel<D, NST, QT, WPS>>(smem);
   dim3 grid(cdiv(p.Lq, 128 * QT) * p.H * p.B);
   hipLaunchKernelGGL((attn2_kernel<D, NST, QT, WPS>), grid, dim3(256), smem, stream, p);
   MD_CHECK_LAUNCH("md_attention_fwd");
@@ -401,8 +397,7 @@ template <int D>
 static int launch_attn2(const AttnParams& p, hipStream_t stream) {
   // two 32-row q-tiles per wave (independent softmax chains interleave with the other tile's MFMAs and every K / V^T
   // fragment read feeds two MFMAs) when the head dim leaves the registers for it and there are enough query rows
-  static int qt_env = -1;
-  if (qt_env < 0) qt_env = getenv("MD_ATTN_QT") ? atoi(getenv("MD_ATTN_QT")) : 0;
+  static const int qt_env = md_env_int("MD_ATTN_QT", 0);
   if constexpr (D <= 80) {
     const bool two = qt_env == 2;   // measured slower on MI355X (1 wave/SIMD, the compiler does not interleave the chains)
     if (two) return launch_attn2_qt<D, 2>(p, stream);

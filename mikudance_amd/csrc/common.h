@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -48,3 +49,25 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time, PER-DEVICE opt-in to more than 64 KiB of dynamic LDS for kernel `Kernel` (hipFuncSetAttribute is a per-device
+// property of the function), safe to call from any number of host threads: a bit per device in an atomic mask; two threads
+// racing on the same device both set the same value, which is harmless.  `Kernel` is a template VALUE parameter so that every
+// kernel instantiation owns its own mask.
+#include <atomic>
+template <auto Kernel>
+static inline void md_ensure_dynamic_lds(int bytes) {
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
+
+// Tuning knobs are read from the environment once per process (function-local statics: thread-safe initialisation).
+static inline int md_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}

@@ -454,25 +454,17 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
 //   big: 256x128, BK=64 x 3 stages = 144 KiB, 8 waves, 1 workgroup/CU, two 48-KiB tiles in flight
 template <bool CONV, bool GEGLU, int NJ, int BK, int NSTAGE, int WM = 2, int WPS = 1, int MI = 2>
 static void launch_variant(GemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
   constexpr int BN = 64 * NJ;
   constexpr size_t ring = (size_t)NSTAGE * (WM * 32 * MI + BN) * BK * 2;
   constexpr size_t cs = (size_t)64 * (BN + 4) * 4;
   constexpr size_t smem = GEGLU ? ring : (ring > cs ? ring : cs);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ, MI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  md_ensure_dynamic_lds<gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ, MI>>((int)smem);
   p.tiles_n = cdiv(p.N, BN);
   p.tiles_total = cdiv(p.M, WM * 32 * MI) * p.tiles_n;
   hipLaunchKernelGGL((gemm_kernel<CONV, BK, NSTAGE, WM, WPS, GEGLU, NJ, MI>), dim3(p.tiles_total), dim3(WM * 128), smem, stream, p);
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
+static int env_int(const char* name, int dflt) { return md_env_int(name, dflt); }
 
 #include "gemm_pp.h"
 #include "gemm_ws.h"
@@ -480,11 +472,7 @@ static int env_int(const char* name, int dflt) {
 template <int KS, int CB, bool RES, bool RA>
 static void launch_ws_variant(const WsParams& p, hipStream_t stream) {
   using Cfg = WsCfg<KS, CB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wsgemm_kernel<KS, CB, RES, RA>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
-    attr_set = true;
-  }
+  md_ensure_dynamic_lds<wsgemm_kernel<KS, CB, RES, RA>>(Cfg::SMEM);
   hipLaunchKernelGGL((wsgemm_kernel<KS, CB, RES, RA>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
 }
 
@@ -516,20 +504,16 @@ static bool ws_eligible(const GemmParams& p) {
 
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
-  static int variant = -1, big = -1, narrow = -1, pp = -1;
-  if (variant < 0) {
-    variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
-    big = env_int("MD_GEMM_BIG", -1);   // -1: automatic
-    narrow = env_int("MD_GEMM_NARROW", 0);
-    pp = env_int("MD_GEMM_PP", 2);      // 0: off, 1: every eligible problem, 2: automatic
-  }
+  static const int variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
+  static const int big = env_int("MD_GEMM_BIG", -1);       // -1: automatic
+  static const int narrow = env_int("MD_GEMM_NARROW", 0);
+  static const int pp = env_int("MD_GEMM_PP", 2);          // 0: off, 1: every eligible problem, 2: automatic
   // ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
   // loop long enough to amortise its prologue / epilogue, which no other workgroup covers.  Same-box A/B on MI355X:
   // +25..28 % on the 96x96 convs (950-1000 TF), +16 % on M=294912 N=320 K=1280, +3..6 % on the K >= 640 GEGLU GEMMs and the
   // 48x48 convs with K >= 5760; slower on the 24x24 / 12x12 levels (288 / 72 tiles) and on K = 320.
   if constexpr (!CONV && !GEGLU) {
-    static int ws = -1;
-    if (ws < 0) ws = env_int("MD_GEMM_WS", 2);      // 0: off, 1: K = 320, 2: K = 320 and K = 640
+    static const int ws = env_int("MD_GEMM_WS", 2);   // 0: off, 1: K = 320, 2: K = 320 and K = 640
     if (ws > 0 && ws_eligible(p) && (p.K == 320 || ws >= 2)) {
       if (p.K == 320) launch_ws<10, 5>(p, stream);
       else launch_ws<20, 2>(p, stream);
@@ -542,8 +526,7 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
     const long fill = tiles * 100 / (rounds * 256);               // % of the CU-rounds that carry a tile
     if constexpr (GEGLU) {
       // persistent flavour (gemm_ppg_kernel): the DMA ring runs across output tiles, so short K loops pay no prologue
-      static int persist = -1;
-      if (persist < 0) persist = env_int("MD_GEMM_PP_PERSIST", 1);
+      static const int persist = env_int("MD_GEMM_PP_PERSIST", 1);
       if (persist && (pp == 1 || (tiles >= 256 && p.K >= (persist == 2 ? 256 : 640)))) {
         launch_ppg(p, stream);
         return;
@@ -603,6 +586,14 @@ static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
   }
   if (p.transpose_out) MD_CHECK_ARG(!p.residual && !p.rowadd && p.act == ACT_NONE, "md_gemm: transposed store supports bias only");
   if (p.rowadd) MD_CHECK_ARG(p.rows_per_group > 0, "md_gemm: rows_per_group must be > 0 with rowadd");
+  if (p.residual && p.residual != p.C) {
+    // in-place residual is part of the contract (header: Aliasing); anything else that overlaps the output is not
+    const uintptr_t c0 = reinterpret_cast<uintptr_t>(p.C), r0 = reinterpret_cast<uintptr_t>(p.residual);
+    const size_t cbytes = ((size_t)(p.M - 1) * p.ldc + p.N) * 2, rbytes = ((size_t)(p.M - 1) * p.ldr + p.N) * 2;
+    MD_CHECK_ARG(p.transpose_out || r0 + rbytes <= c0 || c0 + cbytes <= r0, "md_gemm: residual partially overlaps the output");
+  } else if (p.residual) {
+    MD_CHECK_ARG(p.ldr == p.ldc, "md_gemm: in-place residual needs ldr == ldc");
+  }
   if (conv)
     launch_any<true, false>(p, stream);
   else if (p.act == ACT_GEGLU)

@@ -391,11 +391,7 @@ static void launch_pp_g(GemmParams& p, hipStream_t stream) {
   constexpr size_t ring = (size_t)4 * (256 + BN) * 64;
   constexpr size_t cs = (size_t)64 * (BN + 4) * 4;
   constexpr size_t smem = ring > cs ? ring : cs;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<CONV, GEGLU, NJ, PM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  md_ensure_dynamic_lds<gemm_pp_kernel<CONV, GEGLU, NJ, PM>>((int)smem);
   p.tiles_n = p.N / BN;
   p.tiles_total = cdiv(p.M, 256) * p.tiles_n;
   hipLaunchKernelGGL((gemm_pp_kernel<CONV, GEGLU, NJ, PM>), dim3(p.tiles_total), dim3(512), smem, stream, p);
@@ -403,8 +399,7 @@ static void launch_pp_g(GemmParams& p, hipStream_t stream) {
 
 template <bool CONV, bool GEGLU>
 static void launch_pp(GemmParams& p, hipStream_t stream) {
-  static int pm = -1;
-  if (pm < 0) pm = env_int("MD_GEMM_PP_PM", 1);
+  static const int pm = env_int("MD_GEMM_PP_PM", 1);
   if (pm == 0) launch_pp_g<CONV, GEGLU, 0>(p, stream);
   else launch_pp_g<CONV, GEGLU, 1>(p, stream);
 }
@@ -612,16 +607,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ppg_kernel(GemmParams p) {
 
 static void launch_ppg(GemmParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)4 * (256 + 256) * 64;
-  static bool attr_set = false;
-  static int ncu = 0;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ppg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    int dev = 0;
+  md_ensure_dynamic_lds<gemm_ppg_kernel>((int)smem);
+  static const int ncu = [] {                                    // MI355X: 256 CUs (one persistent workgroup each)
+    int dev = 0, n = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0 || (ncu & 7)) ncu = 256;
-    attr_set = true;
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    return (n <= 0 || (n & 7)) ? 256 : n;
+  }();
   p.tiles_n = p.N / 256;
   p.tiles_total = cdiv(p.M, 256) * p.tiles_n;
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;

@@ -127,11 +127,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 
 template <int FMAX>
 static void launch_temporal(const TemporalParams& p, int grid, int threads, size_t smem, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attn_kernel<FMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  md_ensure_dynamic_lds<temporal_attn_kernel<FMAX>>(96 * 1024);
   hipLaunchKernelGGL(temporal_attn_kernel<FMAX>, dim3(grid), dim3(threads), smem, st, p);
 }
 

@@ -232,6 +232,9 @@ class AutoencoderKL(_Packed):
         if layers_per_block != 2 or norm_num_groups != GROUPS or act_fn != "silu":
             raise ValueError("AutoencoderKL: only the sd-vae-ft-mse family (2 layers per block, 32 groups, SiLU) is built")
         chans = tuple(block_out_channels)
+        if any(c % 64 for c in chans):
+            raise ValueError(f"AutoencoderKL (MI355X): block_out_channels {chans} must be multiples of 64 (the conv / GEMM kernels tile "
+                             "the channel dimension by 64; sd-vae-ft-mse is (128, 256, 512, 512))")
         self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, block_out_channels=chans,
                                       latent_channels=latent_channels, layers_per_block=2, norm_num_groups=GROUPS, act_fn="silu",
                                       scaling_factor=scaling_factor, sample_size=sample_size)

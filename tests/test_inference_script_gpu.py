@@ -60,7 +60,7 @@ def test_inference_video_script_end_to_end(tmp_path, golden_dir):
     torch.save({k: v for k, v in den_sd.items() if k.startswith("conv_in.")}, root / "denoising_unet.pth")        # strict=False
     del den_sd
     torch.save(cheap_state_dict(lambda: M.UNet2DConditionModel(cross_attention_dim=768), 2), root / "reference_unet.pth")
-    vae_cfg = {"_class_name": "AutoencoderKL", "in_channels": 3, "out_channels": 3, "block_out_channels": [32, 64, 64, 64], "latent_channels": 4,
+    vae_cfg = {"_class_name": "AutoencoderKL", "in_channels": 3, "out_channels": 3, "block_out_channels": [64, 64, 128, 128], "latent_channels": 4,
                "layers_per_block": 2, "norm_num_groups": 32, "act_fn": "silu", "scaling_factor": 0.18215, "sample_size": 256}
     json.dump(vae_cfg, open(vae_d / "config.json", "w"))
     save_file(cheap_state_dict(lambda: M.AutoencoderKL(**vae_cfg), 3), str(vae_d / "diffusion_pytorch_model.safetensors"))

@@ -111,6 +111,20 @@ def test_gemm_weight_stationary_streaming_kernel(dev, M, N, K):
         assert float(wide_c[:, :32].abs().max()) == 0.0
 
 
+def test_gemm_residual_aliasing_contract(dev):
+    """include/mdance_hip.h 'Aliasing': residual == output (same pointer, same pitch) is supported by every GEMM flavour the
+    dispatcher can pick; a residual that partially overlaps the output is refused."""
+    from mikudance_amd._lib import MdanceHipError
+    for M, N, K in [(300, 320, 320), (4608, 1280, 1280), (40000, 320, 320)]:
+        a, w, r = rnd(M, K, seed=95), rnd(N, K, seed=96, scale=K ** -0.5), rnd(M, N, seed=97)
+        hs = r.to(dev).clone()
+        ops.gemm(a.to(dev), w.to(dev), residual=hs, out=hs)
+        close(hs, a.float() @ w.float().t() + r.float(), what=f"in-place residual M={M}")
+    buf = torch.zeros(301, 320, device=dev, dtype=torch.float16)
+    with pytest.raises(MdanceHipError, match="overlaps"):
+        ops.gemm(rnd(300, 320).to(dev), rnd(320, 320).to(dev), residual=buf[1:], out=buf[:300])
+
+
 def test_gemm_rejects_bad_k(dev):
     from mikudance_amd._lib import MdanceHipError
     with pytest.raises(MdanceHipError):
