@@ -491,6 +491,26 @@ static void launch_ws(const GemmParams& g, hipStream_t stream) {
   else launch_ws_variant<KS, CB, false, false>(p, stream);
 }
 
+// GEGLU flavour of the streaming kernel: K = 320, packed N % 256 == 0 (128 output columns per workgroup), long M
+static bool ws_geglu_eligible(const GemmParams& p) {
+  if (p.act != ACT_GEGLU || p.K != 320 || p.N % 256 || p.N / 256 > 16 || p.M < 32768 || p.M % 16) return false;
+  if (p.lda % 8 || p.ldc % 8) return false;
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return al(p.A) && al(p.W) && al(p.C) && al(p.bias);
+}
+
+static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
+  using Cfg = WsCfg<10, 4>;
+  WsParams p;
+  p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = nullptr; p.rowadd = nullptr;
+  p.lda = g.lda; p.ldc = g.ldc; p.ldr = 0; p.ldra = 0; p.M = g.M; p.N = g.N; p.rows_per_group = 1;
+  p.groups = g.N / Cfg::GC;
+  p.spx = 32 / p.groups;
+  p.streams = 8 * p.spx;
+  md_ensure_dynamic_lds<wsgemm_kernel<10, 4, false, false, true>>(Cfg::SMEM);
+  hipLaunchKernelGGL((wsgemm_kernel<10, 4, false, false, true>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+}
+
 // W-stationary streaming kernel (gemm_ws.h): plain epilogues, K = 320 (N % 320 == 0) or K = 640 (N % 128 == 0), long M.
 static bool ws_eligible(const GemmParams& p) {
   if (p.act != ACT_NONE || p.transpose_out || p.M < 32768 || p.M % 16) return false;
@@ -517,6 +537,13 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
     if (ws > 0 && ws_eligible(p) && (p.K == 320 || ws >= 2)) {
       if (p.K == 320) launch_ws<10, 5>(p, stream);
       else launch_ws<20, 2>(p, stream);
+      return;
+    }
+  }
+  if constexpr (!CONV && GEGLU) {
+    static const int wsg = env_int("MD_GEMM_WS_GEGLU", 1);
+    if (wsg > 0 && ws_geglu_eligible(p)) {
+      launch_ws_geglu(p, stream);
       return;
     }
   }

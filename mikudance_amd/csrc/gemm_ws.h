@@ -30,7 +30,8 @@
 #define WS_RES_DEPTH 4
 #endif
 #ifndef WS_COMPUTE_PIECES
-#define WS_COMPUTE_PIECES -1   // DMA pieces per tile issued by each compute wave (-1: default split)
+#define WS_COMPUTE_PIECES 0    // DMA pieces per tile issued by each compute wave.  0: the two loader waves issue them all.
+                               // (> 0 measured no faster and produced rare corrupted first tiles on MI355X: not used.)
 #endif
 
 struct WsParams {
@@ -57,11 +58,12 @@ struct WsCfg {
   static constexpr int STAGE = TR * K * 2;        // bytes per A stage
   static constexpr int CS_LD = GC + 4;            // fp32 staging pitch (floats): rows shift by 4 banks
   static constexpr int CSTAGE = TR * CS_LD * 4;
-  static constexpr int NS = (160 * 1024 - 2 * CSTAGE) / STAGE > 12 ? 12 : (160 * 1024 - 2 * CSTAGE) / STAGE;
+  static constexpr int OSTAGE = 4096;             // GEGLU hand-off buffers (2 x 2 KiB); reserved in every flavour
+  static constexpr int NS = (160 * 1024 - 2 * CSTAGE - OSTAGE) / STAGE > 12 ? 12 : (160 * 1024 - 2 * CSTAGE - OSTAGE) / STAGE;
   static constexpr int DPT = STAGE / 1024;        // DMA wave-instructions per tile
-  static constexpr int CP = WS_COMPUTE_PIECES < 0 ? (KS <= 10 ? 1 : 3) : WS_COMPUTE_PIECES;   // pieces per tile issued by each compute wave
+  static constexpr int CP = WS_COMPUTE_PIECES;    // pieces per tile issued by each compute wave
   static constexpr int PER = (DPT - 4 * CP) / 2;  // ... by each of the two loader waves
-  static constexpr int SMEM = NS * STAGE + 2 * CSTAGE;
+  static constexpr int SMEM = NS * STAGE + 2 * CSTAGE + OSTAGE;
   static constexpr int CHUNKS = TR * GC / 8;      // 16-byte output pieces per tile
   static constexpr int SPL = CHUNKS / 128;        // ... per lane of the two store waves
   static constexpr int PD = KS <= 10 ? 3 : 6;     // A fragments in flight per compute wave (register budget: 256 per wave)
@@ -74,13 +76,33 @@ __device__ __forceinline__ int ws_swz(int row) {
   return CPR == 40 ? ((row >> 1) & 7) : (row & 15);
 }
 
-template <int KS, int CB, bool RES, bool RA>
+// GEGLU flavour: one 16-byte output piece = 8 columns of (h + b_h) * gelu_erf(g + b_g) from the fp32 staging tile.
+struct WsGegluPiece {
+  int row, hcol;            // staging row, staging column of h (g sits 32 columns further)
+  float bh[8], bg[8];
+};
+__device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, const WsGegluPiece& q) {
+  const float* s = cs + q.row * cs_ld + q.hcol;
+  const floatx4 h0 = *reinterpret_cast<const floatx4*>(s), h1 = *reinterpret_cast<const floatx4*>(s + 4);
+  const floatx4 g0 = *reinterpret_cast<const floatx4*>(s + 32), g1 = *reinterpret_cast<const floatx4*>(s + 36);
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (half_t)((h0[j] + q.bh[j]) * gelu_fast(g0[j] + q.bg[j]));
+    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gelu_fast(g1[j] + q.bg[j + 4]));
+  }
+  return o;
+}
+
+template <int KS, int CB, bool RES, bool RA, bool GEGLU = false>
 __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
+  static_assert(!GEGLU || (CB == 4 && !RES && !RA), "GEGLU: 2 h + 2 g column blocks per compute wave, bias only");
   using Cfg = WsCfg<KS, CB>;
   constexpr int K = Cfg::K, CPR = Cfg::CPR, GC = Cfg::GC, TR = Cfg::TR, STAGE = Cfg::STAGE, NS = Cfg::NS, CS_LD = Cfg::CS_LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
   float* cst = reinterpret_cast<float*>(smem + NS * STAGE);
+  char* ost = smem + NS * STAGE + 2 * Cfg::CSTAGE;   // GEGLU only: 2 x 2 KiB of finished fp16 pieces handed from loader to store waves
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // workgroup -> (XCD, column group, row stream): the G groups of one row stream share an XCD (blockIdx % 8)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -91,6 +113,23 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   const int my_tiles = stream < ntiles ? (ntiles - stream + p.streams - 1) / p.streams : 0;   // tiles stream, stream+S, ...
   if (my_tiles == 0) return;
   const int n0 = grp * GC;
+  // GEGLU: the GELU arithmetic (two transcendentals + ~14 VALU per output) is the longest job of a tile, so all FOUR memory
+  // waves share it: piece id = (wave - 4) * 64 + lane of the tile's 256 pieces.  The store waves write theirs to global memory;
+  // the loader waves (whose vmcnt must see nothing but their DMAs) park theirs in LDS and the store waves ship them one tile
+  // later.  One extra barrier at the end drains that pipeline stage.
+  WsGegluPiece gp = {};
+  if constexpr (GEGLU) {
+    if (wave >= 4) {
+      const int id = (wave - 4) * 64 + lane;
+      gp.row = id / (GC / 16);
+      const int oc = (id % (GC / 16)) * 8;
+      gp.hcol = 64 * (oc >> 5) + (oc & 31);
+      const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol + 32) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gp.bh[j] = (float)b0[j], gp.bg[j] = (float)b1[j];
+    }
+  }
 
   if (wave < 4) {
     // ------------------------------------------------------------------------------------------------ compute waves
@@ -173,8 +212,13 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       float* cs = cst + (it & 1) * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
+      // A raw s_barrier does not wait for this wave's LDS stores (gfx950 has the back-off barrier, so the compiler adds no
+      // s_waitcnt either), and a store wave on the other SIMD pair can have its ds_read serviced before them: the staging tile
+      // must be WRITTEN, not just issued, before the next barrier hands it over (seen as stale / uninitialised staging data).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                   // b_{my_tiles}: the last staging tile is complete
+    if constexpr (GEGLU) __builtin_amdgcn_s_barrier();   // b_{my_tiles + 1}
   } else if (wave < 6) {
     // ------------------------------------------------------------------------------------------------ loader waves
     // per-lane source pointers are tile invariant up to a constant stride (M % 16 == 0 is a launch precondition, so no row
@@ -197,6 +241,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         sp[i] += astep;
       }
     };
+    if constexpr (GEGLU) __builtin_amdgcn_s_waitcnt(0x0F70);      // the bias loads above: nothing but DMAs may be counted below
     const int pre = my_tiles < NS - 1 ? my_tiles : NS - 1;
     for (int it = 0; it < pre; ++it) issue(it);
     for (int it = 0; it < my_tiles; ++it) {
@@ -205,10 +250,46 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();                 // also: the compute waves are done with tile it-1 -> its stage is free
       if (it + NS - 1 < my_tiles) issue(it + NS - 1);   // into stage (it - 1) % NS
+      if constexpr (GEGLU) {
+        if (it >= 1) {                              // this wave's piece of tile it-1 -> LDS (shipped by a store wave after b_{it+1})
+          const half8_t o = ws_geglu_piece(cst + ((it - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          *reinterpret_cast<half8_t*>(ost + ((it - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
     }
     __builtin_amdgcn_s_barrier();                   // b_{my_tiles}
+    if constexpr (GEGLU) {
+      const half8_t o = ws_geglu_piece(cst + ((my_tiles - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+      *reinterpret_cast<half8_t*>(ost + ((my_tiles - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // b_{my_tiles + 1}
+    }
   } else {
     // ------------------------------------------------------------------------------------------------ store waves
+    if constexpr (GEGLU) {
+      // FeedForward net.0 (GEGLU, reference src/models/attention.py:152-157 / diffusers FeedForward): the weight rows are packed
+      // in blocks of 32 h rows then 32 g rows (packing.geglu_weight), so compute wave w owns exactly one block: staging columns
+      // [64w, 64w+32) hold h and [64w+32, 64w+64) hold g of output columns [32w, 32w+32) of this workgroup.  out = (h + b_h) *
+      // gelu_erf(g + b_g), one rounding, 16-byte stores into the [M][N/2] output.
+      constexpr int OC = GC / 2;
+      const int sw2 = wave - 6;                                          // 0 / 1: ships the pieces of loader wave sw2 as well
+      const int id_own = (wave - 4) * 64 + lane, id_ld = sw2 * 64 + lane;
+      const size_t cstep = (size_t)p.streams * TR * p.ldc;
+      half_t* cp_own = p.C + (size_t)(stream * TR + id_own / (OC / 8)) * p.ldc + grp * OC + (id_own % (OC / 8)) * 8;
+      half_t* cp_ld = p.C + (size_t)(stream * TR + id_ld / (OC / 8)) * p.ldc + grp * OC + (id_ld % (OC / 8)) * 8;
+      for (int it = 0; it <= my_tiles + 1; ++it) {
+        __builtin_amdgcn_s_barrier();                                   // b_it
+        if (it >= 2) {                                                  // loader pieces of tile it-2, parked in LDS at iteration it-1
+          *reinterpret_cast<half8_t*>(cp_ld) = *reinterpret_cast<const half8_t*>(ost + ((it - 2) & 1) * 2048 + id_ld * 16);
+          cp_ld += cstep;
+        }
+        if (it >= 1 && it <= my_tiles) {                                // own piece of tile it-1
+          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece(cst + ((it - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          cp_own += cstep;
+        }
+      }
+    } else {
     // Lean on purpose: two waves move every output byte of the workgroup, so per 16-byte piece the loop is 2 LDS reads,
     // 8 fp32 adds per epilogue term, 4 packed converts, a 64-bit pointer bump and the store.  Pointers advance by a constant
     // per tile; bias / row-broadcast terms live in registers as floats; only the last tile of a stream can be ragged.
@@ -326,6 +407,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           }
         }
       }
+    }
     }
   }
 }

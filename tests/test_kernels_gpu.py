@@ -87,6 +87,25 @@ def test_gemm_geglu(dev):
     close(out, ref, what="geglu")
 
 
+@pytest.mark.parametrize("M,inner", [(40000, 1280), (294912, 1280), (33024, 256)])
+def test_gemm_geglu_weight_stationary_streaming_kernel(dev, M, inner):
+    """FeedForward net.0 at C = 320 (K = 320, N = 8C packed h|g, M >= 32768): the GEGLU flavour of the streaming kernel, whose four
+    memory waves share the GELU arithmetic (two of them hand their finished pieces through LDS).  Every element is checked, three
+    launches each (the hand-off pipeline has a one-tile skew: a synchronisation slip shows up as stale pieces)."""
+    K = 320
+    a = rnd(M, K, seed=21)
+    w, b = rnd(2 * inner, K, seed=22, scale=K ** -0.5), rnd(2 * inner, seed=23)
+    wp, bp = packing.geglu_weight(w, b, dev)
+    ad = a.to(dev)
+    hg = ad.float() @ w.to(dev).float().t() + b.to(dev).float()
+    ref = (hg[:, :inner] * F.gelu(hg[:, inner:])).cpu()
+    del hg
+    for _ in range(3):
+        out = ops.gemm(ad, wp, bias=bp, act=ops.ACT_GEGLU)
+        assert out.shape == (M, inner)
+        close(out, ref, what="ws geglu")
+
+
 @pytest.mark.parametrize("M,N,K", [(40000, 320, 320), (32771, 960, 320), (36000, 640, 640), (33001, 128, 640), (294912, 320, 320)])
 def test_gemm_weight_stationary_streaming_kernel(dev, M, N, K):
     """The W-stationary streaming GEMM (gemm_ws.h) that the dispatcher picks for the HBM-bound short-K projections
