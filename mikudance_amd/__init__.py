@@ -17,5 +17,6 @@ from .scheduler import DDIMScheduler  # noqa: F401
 from .unet_2d_mix import UNet2DConditionModel, UNet2DConditionModelPlain  # noqa: F401
 from .unet_3d_mix import UNet3DConditionModel  # noqa: F401
 from .vae import AutoencoderKL  # noqa: F401
+from .vae_temporal import AutoencoderKLTemporalDecoder  # noqa: F401
 
 __version__ = "0.1.0"

@@ -15,7 +15,7 @@ has (no omegaconf / diffusers / PyAV / cv2 / torchvision / scikit-image): see mi
     pipe(ref_image, ref_skel, pose, face, hand, scene_motion, W, H, F, steps, cfg, generator)      (:211-224)
     save_videos_grid(cat([ref, pose, video]), ".../{skel}_{ref}_{H}x{W}_{cfg}_{time}.mp4", n_rows=3, fps)     (:228-234)
 
-`--video_decoder` (AutoencoderKLTemporalDecoder) is not implemented here and says so."""
+`--video_decoder` selects mikudance_amd.AutoencoderKLTemporalDecoder (config.pretrained_temporal_vae_path), like the reference (:72-75)."""
 import argparse
 import os
 from datetime import datetime
@@ -25,8 +25,8 @@ import numpy as np
 import torch
 from PIL import Image
 
-from . import (AutoencoderKL, CLIPVisionModelWithProjection, DDIMScheduler, MikuDanceVideoPipeline, UNet2DConditionModel,
-               UNet2DConditionModelPlain, UNet3DConditionModel)
+from . import (AutoencoderKL, AutoencoderKLTemporalDecoder, CLIPVisionModelWithProjection, DDIMScheduler, MikuDanceVideoPipeline,
+               UNet2DConditionModel, UNet2DConditionModelPlain, UNet3DConditionModel)
 from .io_utils import frames_to_tensor, get_fps, load_config, read_frames, resize_depth, save_videos_grid, to_container
 from .scene_motion import camera_to_scene_motion
 
@@ -53,9 +53,9 @@ def _none(v):
 def build_pipeline(config, infer_config, weight_dtype, device="cuda", video_decoder=False):
     """scripts/inference_video.py:72-130."""
     if video_decoder:
-        raise NotImplementedError("--video_decoder (AutoencoderKLTemporalDecoder) is not implemented on the MI355X path; "
-                                  "the default per-frame AutoencoderKL decode is")
-    vae = AutoencoderKL.from_pretrained(config.pretrained_vae_path).to(device, dtype=weight_dtype)
+        vae = AutoencoderKLTemporalDecoder.from_pretrained(config.pretrained_temporal_vae_path).to(device, dtype=weight_dtype)
+    else:
+        vae = AutoencoderKL.from_pretrained(config.pretrained_vae_path).to(device, dtype=weight_dtype)
     unet = UNet2DConditionModelPlain.from_pretrained(config.pretrained_base_model_path, subfolder="unet")
     reference_unet = UNet2DConditionModel.from_unet(unet)
     del unet

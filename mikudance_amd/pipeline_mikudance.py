@@ -80,6 +80,7 @@ class MikuDanceVideoPipeline:
         self.reference_unet, self.denoising_unet, self.scheduler = reference_unet, denoising_unet, scheduler
         self.image_proj_model, self.tokenizer, self.text_encoder = image_proj_model, tokenizer, text_encoder
         self.video_decoder = video_decoder
+        self.decode_chunk_size = 16                                          # reference :81
         self.vae_scale_factor = 8
         self.reference_reuse = True
         self._device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
@@ -245,8 +246,9 @@ class MikuDanceVideoPipeline:
         video = (video / 2 + 0.5).clamp(0, 1)
         return video.cpu().float().numpy()
 
-    def decode_temporal(self, latents, decode_chunk_size=16):
-        """reference :132-150 (AutoencoderKLTemporalDecoder in chunks of 16)."""
+    def decode_temporal(self, latents, decode_chunk_size=None):
+        """reference :132-150 (AutoencoderKLTemporalDecoder in chunks of self.decode_chunk_size = 16 frames)."""
+        decode_chunk_size = decode_chunk_size or self.decode_chunk_size
         video_length = latents.shape[2]
         latents = 1 / 0.18215 * latents
         latents = latents.permute(0, 2, 1, 3, 4).reshape((-1,) + tuple(latents.shape[1:2]) + tuple(latents.shape[3:]))

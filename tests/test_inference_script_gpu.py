@@ -101,5 +101,14 @@ def test_inference_video_script_end_to_end(tmp_path, golden_dir):
     assert len(frames) == F_ and frames[0].size == (3 * (W + 2) + 2, H + 4) and U.get_fps(out) == 12
     a = np.asarray(frames[0], dtype=np.float32)
     assert np.isfinite(a).all() and a[:, 2 * (W + 2):].std() > 0                     # third grid cell = the generated frame
-    with pytest.raises(NotImplementedError):
-        inference_video.main(["--config", str(tmp_path / "configs" / "inference_video.yaml"), "--video_decoder"])
+    # --video_decoder: the temporal-decoder VAE (config.pretrained_temporal_vae_path), frames decoded in chunks with num_frames
+    tv = root / "vae_temporal_decoder"
+    os.makedirs(tv)
+    tcfg = {"_class_name": "AutoencoderKLTemporalDecoder", "in_channels": 3, "out_channels": 3, "block_out_channels": [64, 64, 128, 128],
+            "latent_channels": 4, "layers_per_block": 2, "sample_size": 768, "scaling_factor": 0.18215, "force_upcast": True}
+    json.dump(tcfg, open(tv / "config.json", "w"))
+    save_file(cheap_state_dict(lambda: M.AutoencoderKLTemporalDecoder(**tcfg), 5), str(tv / "diffusion_pytorch_model.safetensors"))
+    out2 = inference_video.main(["--config", str(tmp_path / "configs" / "inference_video.yaml"), "-W", str(W), "-H", str(H), "--steps", "1",
+                                 "--seed", "7", "--video_decoder", "--output_dir", str(tmp_path / "output_t")])
+    f2 = U.read_frames(out2)
+    assert len(f2) == F_ and f2[0].size == frames[0].size and np.isfinite(np.asarray(f2[0], dtype=np.float32)).all()

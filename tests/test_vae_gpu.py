@@ -83,3 +83,39 @@ def test_autoencoder_kl_vs_oracle(chans, hw):
     assert r < 3e-2 and c > 0.999, ("decode", r, c)
     s = post.sample(torch.Generator().manual_seed(1))
     assert s.shape == post.mean.shape and torch.isfinite(s.float()).all()
+
+
+@pytest.mark.parametrize("chans,frames,clips", [((64, 128), 3, 1), ((64, 128, 128, 128), 4, 2), ((64, 64), 1, 2)])
+def test_temporal_decoder_vs_oracle(chans, frames, clips):
+    """AutoencoderKLTemporalDecoder.decode (`--video_decoder`): frame-shifted token GEMMs for the Conv3d(3,1,1)s,
+    clip-wide GroupNorm, the learned spatial/temporal blend folded into the second temporal conv -- against the F.conv3d
+    restatement (oracle, unpinned), several clips per call, and the encoder path it shares with AutoencoderKL."""
+    from mikudance_amd import AutoencoderKLTemporalDecoder
+    vae = AutoencoderKLTemporalDecoder(block_out_channels=chans)
+    shapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    assert tuple(shapes["decoder.time_conv_out.weight"]) == (3, 3, 3, 1, 1) and "post_quant_conv.weight" not in shapes
+    assert tuple(shapes["decoder.mid_block.resnets.0.temporal_res_block.conv1.weight"]) == (chans[-1], chans[-1], 3, 1, 1)
+    assert tuple(shapes["decoder.up_blocks.0.resnets.2.time_mixer.mix_factor"]) == (1,)
+    sd = synth_state_dict(shapes, seed=31)
+    for k in sd:
+        if k.endswith("mix_factor"):
+            sd[k] = torch.tensor([0.7 if "mid" in k else -0.4])
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.to("cuda", dtype=torch.float16)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(clips * frames, 4, 8, 4, generator=g)
+    with torch.no_grad():
+        want = O.vae_temporal_decode(sd, z, frames)
+    got = vae.decode(z.cuda().half(), num_frames=frames).sample
+    up = 2 ** (len(chans) - 1)
+    assert tuple(got.shape) == (clips * frames, 3, 8 * up, 4 * up)
+    r, c = rel_l2(got.float(), want), cosine(got.float(), want)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    if frames > 1:                                                    # the frames really talk to each other
+        alone = torch.cat([O.vae_temporal_decode(sd, z[i:i + 1], 1) for i in range(z.shape[0])])
+        assert rel_l2(alone, want) > 5 * r
+    x = torch.randn(2, 3, 8 * up, 8 * up, generator=g)
+    m = vae.encode(x.cuda().half()).latent_dist.mean
+    assert rel_l2(m.float(), O.vae_encode_moments(sd, x)[:, :4]) < 3e-2
+    with pytest.raises(ValueError):
+        vae.decode(z[:frames * clips - 1].cuda().half(), num_frames=frames) if frames > 1 else vae.decode(z[:, :3].cuda().half())
