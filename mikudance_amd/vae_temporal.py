@@ -211,9 +211,10 @@ class AutoencoderKLTemporalDecoder(_Packed):
         h = self.encoder(ops.pack_nhwc(x, B, 1, (st[0], 0, st[1], st[2], st[3]), 0, C, 64, H, W))
         m64 = torch.zeros_like(h)
         ops.gemm(tokens(h), pk["q"], bias=pk["qb"], out=tokens(m64)[:, :2 * self.zc])
-        moments = torch.empty((B, 2 * self.zc, H // 8, W // 8), device=x.device, dtype=x.dtype if x.dtype != torch.float64 else torch.float32)
+        hl, wl = h.shape[1], h.shape[2]
+        moments = torch.empty((B, 2 * self.zc, hl, wl), device=x.device, dtype=x.dtype if x.dtype != torch.float64 else torch.float32)
         so = moments.stride()
-        ops.unpack_nhwc(m64, moments, B, 1, (so[0], 0, so[1], so[2], so[3]), 2 * self.zc, H // 8, W // 8)
+        ops.unpack_nhwc(m64, moments, B, 1, (so[0], 0, so[1], so[2], so[3]), 2 * self.zc, hl, wl)
         out = SimpleNamespace(latent_dist=DiagonalGaussian(moments))
         return out if return_dict else (out.latent_dist,)
 
@@ -228,9 +229,10 @@ class AutoencoderKLTemporalDecoder(_Packed):
         z64 = ops.pack_nhwc(z, B, 1, (st[0], 0, st[1], st[2], st[3]), 0, C, 64, h, w)
         y = self.decoder(z64, num_frames)                                                # (B, 8h, 8w, 8): 3 valid channels
         oc = self.decoder.out_channels
-        img = torch.empty((B, oc, 8 * h, 8 * w), device=z.device, dtype=z.dtype if z.dtype != torch.float64 else torch.float32)
+        H, W = y.shape[1], y.shape[2]                                                    # 2^(levels-1) x the latent size
+        img = torch.empty((B, oc, H, W), device=z.device, dtype=z.dtype if z.dtype != torch.float64 else torch.float32)
         so = img.stride()
-        ops.unpack_nhwc(y, img, B, 1, (so[0], 0, so[1], so[2], so[3]), oc, 8 * h, 8 * w)
+        ops.unpack_nhwc(y, img, B, 1, (so[0], 0, so[1], so[2], so[3]), oc, H, W)
         out = SimpleNamespace(sample=img)
         return out if return_dict else (img,)
 

@@ -99,6 +99,32 @@ def test_non_square_latents_and_odd_frame_count_vs_oracle(small):
     assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
 
 
+def test_reference_unet_dead_tail_skip(small):
+    """The reference UNet's sample after its LAST bank write (last attention of the last up block, in execution order) is
+    discarded by the pipeline: with skip_dead_tail the forward stops there (returns None) and every bank equals the full run's."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    f = 4
+    g = t["in.ref_latents"][:, :f].reshape(f, 22, 16, 16).cuda().half()
+    emb = t["in.embeds"][1:].repeat(f, 1, 1).cuda().half()
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=False, mode="write", batch_size=1, fusion_blocks="full")
+    banks = {}
+    for skip in (False, True):
+        ref.skip_dead_tail = skip
+        try:
+            out = ref(g, torch.zeros((), dtype=torch.long), encoder_hidden_states=emb, return_dict=False)[0]
+        finally:
+            ref.skip_dead_tail = False
+        assert (out is None) == skip
+        blocks = writer._blocks(ref)
+        assert all(len(b.bank) == 1 for b in blocks) and len(blocks) == 16
+        banks[skip] = [b.bank[0].clone() for b in blocks]
+        writer.clear()
+    for a, b in zip(banks[False], banks[True]):
+        assert torch.equal(a, b)
+    for b in writer._blocks(ref):
+        b.ref_mode = None
+
+
 def test_scheduler_step_api(small):
     sch = DDIMScheduler(**SCHED_KWARGS)
     sch.set_timesteps(20)
