@@ -76,24 +76,6 @@ __device__ __forceinline__ int ws_swz(int row) {
   return CPR == 40 ? ((row >> 1) & 7) : (row & 15);
 }
 
-// GEGLU flavour: one 16-byte output piece = 8 columns of (h + b_h) * gelu_erf(g + b_g) from the fp32 staging tile.
-struct WsGegluPiece {
-  int row, hcol;            // staging row, staging column of h (g sits 32 columns further)
-  float bh[8], bg[8];
-};
-__device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, const WsGegluPiece& q) {
-  const float* s = cs + q.row * cs_ld + q.hcol;
-  const floatx4 h0 = *reinterpret_cast<const floatx4*>(s), h1 = *reinterpret_cast<const floatx4*>(s + 4);
-  const floatx4 g0 = *reinterpret_cast<const floatx4*>(s + 32), g1 = *reinterpret_cast<const floatx4*>(s + 36);
-  half8_t o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    o[j] = (half_t)((h0[j] + q.bh[j]) * gelu_fast(g0[j] + q.bg[j]));
-    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gelu_fast(g1[j] + q.bg[j + 4]));
-  }
-  return o;
-}
-
 template <int KS, int CB, bool RES, bool RA, bool GEGLU = false>
 __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   static_assert(!GEGLU || (CB == 4 && !RES && !RA), "GEGLU: 2 h + 2 g column blocks per compute wave, bias only");
@@ -102,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
   float* cst = reinterpret_cast<float*>(smem + NS * STAGE);
-  char* ost = smem + NS * STAGE + 2 * Cfg::CSTAGE;   // GEGLU only: 2 x 2 KiB of finished fp16 pieces handed from loader to store waves
+  char* ost = smem + NS * STAGE + 2 * Cfg::CSTAGE;   // GEGLU only: 2 x 2 KiB of fp16 outputs finished by the compute waves (pair 0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // workgroup -> (XCD, column group, row stream): the G groups of one row stream share an XCD (blockIdx % 8)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -113,24 +95,10 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   const int my_tiles = stream < ntiles ? (ntiles - stream + p.streams - 1) / p.streams : 0;   // tiles stream, stream+S, ...
   if (my_tiles == 0) return;
   const int n0 = grp * GC;
-  // GEGLU: the GELU arithmetic (two transcendentals + ~14 VALU per output) is the longest job of a tile, so all FOUR memory
-  // waves share it: piece id = (wave - 4) * 64 + lane of the tile's 256 pieces.  The store waves write theirs to global memory;
-  // the loader waves (whose vmcnt must see nothing but their DMAs) park theirs in LDS and the store waves ship them one tile
-  // later.  One extra barrier at the end drains that pipeline stage.
-  WsGegluPiece gp = {};
-  if constexpr (GEGLU) {
-    if (wave >= 4) {
-      const int id = (wave - 4) * 64 + lane;
-      gp.row = id / (GC / 16);
-      const int oc = (id % (GC / 16)) * 8;
-      gp.hcol = 64 * (oc >> 5) + (oc & 31);
-      const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol + 32) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gp.bh[j] = (float)b0[j], gp.bg[j] = (float)b1[j];
-    }
-  }
-
+  // GEGLU: the GELU arithmetic (two transcendentals + ~14 VALU per output, ~830 cycles per 8 outputs per lane) is the longest
+  // job of a tile, so it is split between the waves that have slack: every compute wave finishes column pair 0 (its h block 0
+  // and g block 0: 4 outputs per lane, fp16 straight into a small LDS tile) right after its MFMAs -- it idles ~60 % of a tile
+  // otherwise -- and the two store waves finish pair 1 from the fp32 staging tile (8 outputs per lane) and ship both.
   if (wave < 4) {
     // ------------------------------------------------------------------------------------------------ compute waves
     half8_t wf[CB][KS];
@@ -148,6 +116,16 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), expcnt / lgkmcnt untouched
     const int row = lane & 15, kq = lane >> 4;
     const int rbase = row * CPR, sw = ws_swz<CPR>(row);
+    float gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // GEGLU: bias of this lane's 4 h (block 0) and 4 g (block 2) columns
+    if constexpr (GEGLU) {
+      if (p.bias) {
+        const half4_t b0 = *reinterpret_cast<const half4_t*>(p.bias + n0 + wave * 64 + 4 * kq);
+        const half4_t b1 = *reinterpret_cast<const half4_t*>(p.bias + n0 + wave * 64 + 32 + 4 * kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gb[r] = (float)b0[r], gb[4 + r] = (float)b1[r];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
     // the compute waves also issue CP of each tile's DMA pieces (one wave can only issue a piece every few hundred cycles:
     // two loader waves alone cap the tile rate); after the drain above their vmcnt counts nothing but these DMAs
     constexpr int CP = Cfg::CP;
@@ -209,16 +187,26 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                       //     ahead of that step's CB MFMAs
       }
       // acc[cb][r] = C[m = row][n = wave*16CB + cb*16 + 4*kq + r]
-      float* cs = cst + (it & 1) * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
+      if constexpr (GEGLU) {
+        // blocks 0, 1 = h columns 0-15, 16-31 of this wave's 32 outputs, blocks 2, 3 = the matching g columns
+        half4_t o;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc[0][r] + gb[r]) * gelu_fast(acc[2][r] + gb[4 + r]));
+        *reinterpret_cast<half4_t*>(ost + (it & 1) * 2048 + row * 128 + (wave * 16 + 4 * kq) * 2) = o;
+        float* cs = cst + (it & 1) * (TR * CS_LD) + row * CS_LD + wave * 32 + 4 * kq;
+        *reinterpret_cast<floatx4*>(cs) = acc[1];
+        *reinterpret_cast<floatx4*>(cs + 16) = acc[3];
+      } else {
+        float* cs = cst + (it & 1) * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
+      }
       // A raw s_barrier does not wait for this wave's LDS stores (gfx950 has the back-off barrier, so the compiler adds no
       // s_waitcnt either), and a store wave on the other SIMD pair can have its ds_read serviced before them: the staging tile
       // must be WRITTEN, not just issued, before the next barrier hands it over (seen as stale / uninitialised staging data).
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                   // b_{my_tiles}: the last staging tile is complete
-    if constexpr (GEGLU) __builtin_amdgcn_s_barrier();   // b_{my_tiles + 1}
   } else if (wave < 6) {
     // ------------------------------------------------------------------------------------------------ loader waves
     // per-lane source pointers are tile invariant up to a constant stride (M % 16 == 0 is a launch precondition, so no row
@@ -241,7 +229,6 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         sp[i] += astep;
       }
     };
-    if constexpr (GEGLU) __builtin_amdgcn_s_waitcnt(0x0F70);      // the bias loads above: nothing but DMAs may be counted below
     const int pre = my_tiles < NS - 1 ? my_tiles : NS - 1;
     for (int it = 0; it < pre; ++it) issue(it);
     for (int it = 0; it < my_tiles; ++it) {
@@ -250,43 +237,45 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();                 // also: the compute waves are done with tile it-1 -> its stage is free
       if (it + NS - 1 < my_tiles) issue(it + NS - 1);   // into stage (it - 1) % NS
-      if constexpr (GEGLU) {
-        if (it >= 1) {                              // this wave's piece of tile it-1 -> LDS (shipped by a store wave after b_{it+1})
-          const half8_t o = ws_geglu_piece(cst + ((it - 1) & 1) * (TR * CS_LD), CS_LD, gp);
-          *reinterpret_cast<half8_t*>(ost + ((it - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      }
     }
     __builtin_amdgcn_s_barrier();                   // b_{my_tiles}
-    if constexpr (GEGLU) {
-      const half8_t o = ws_geglu_piece(cst + ((my_tiles - 1) & 1) * (TR * CS_LD), CS_LD, gp);
-      *reinterpret_cast<half8_t*>(ost + ((my_tiles - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                 // b_{my_tiles + 1}
-    }
   } else {
     // ------------------------------------------------------------------------------------------------ store waves
     if constexpr (GEGLU) {
       // FeedForward net.0 (GEGLU, reference src/models/attention.py:152-157 / diffusers FeedForward): the weight rows are packed
-      // in blocks of 32 h rows then 32 g rows (packing.geglu_weight), so compute wave w owns exactly one block: staging columns
-      // [64w, 64w+32) hold h and [64w+32, 64w+64) hold g of output columns [32w, 32w+32) of this workgroup.  out = (h + b_h) *
-      // gelu_erf(g + b_g), one rounding, 16-byte stores into the [M][N/2] output.
+      // in blocks of 32 h rows then 32 g rows (packing.geglu_weight), so compute wave w owns exactly one block = output columns
+      // [32w, 32w+32) of this workgroup's 128.  out = (h + b_h) * gelu_erf(g + b_g), one rounding, 16-byte stores into the
+      // [M][N/2] output.  Per tile this lane ships TWO pieces of its row: columns 32w + 8*half (pair 0, finished by compute wave w,
+      // fp16 in LDS) and 32w + 16 + 8*half (pair 1: from the fp32 staging tile, GELU done here).
       constexpr int OC = GC / 2;
-      const int sw2 = wave - 6;                                          // 0 / 1: ships the pieces of loader wave sw2 as well
-      const int id_own = (wave - 4) * 64 + lane, id_ld = sw2 * 64 + lane;
+      const int sid = (wave - 6) * 64 + lane;                         // 0..127 = 16 rows x 4 waves x 2 halves
+      const int prow = sid >> 3, pw = (sid >> 1) & 3, half = sid & 1;
+      float bh[8], bg[8];
+      {
+        const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pw * 64 + 16 + 8 * half) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pw * 64 + 48 + 8 * half) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bh[j] = (float)b0[j], bg[j] = (float)b1[j];
+      }
       const size_t cstep = (size_t)p.streams * TR * p.ldc;
-      half_t* cp_own = p.C + (size_t)(stream * TR + id_own / (OC / 8)) * p.ldc + grp * OC + (id_own % (OC / 8)) * 8;
-      half_t* cp_ld = p.C + (size_t)(stream * TR + id_ld / (OC / 8)) * p.ldc + grp * OC + (id_ld % (OC / 8)) * 8;
-      for (int it = 0; it <= my_tiles + 1; ++it) {
+      half_t* cp0 = p.C + (size_t)(stream * TR + prow) * p.ldc + grp * OC + pw * 32 + 8 * half;
+      for (int it = 0; it <= my_tiles; ++it) {
         __builtin_amdgcn_s_barrier();                                   // b_it
-        if (it >= 2) {                                                  // loader pieces of tile it-2, parked in LDS at iteration it-1
-          *reinterpret_cast<half8_t*>(cp_ld) = *reinterpret_cast<const half8_t*>(ost + ((it - 2) & 1) * 2048 + id_ld * 16);
-          cp_ld += cstep;
-        }
-        if (it >= 1 && it <= my_tiles) {                                // own piece of tile it-1
-          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece(cst + ((it - 1) & 1) * (TR * CS_LD), CS_LD, gp);
-          cp_own += cstep;
+        if (it >= 1) {
+          const int buf = (it - 1) & 1;
+          const float* q = cst + buf * (TR * CS_LD) + prow * CS_LD + pw * 32 + 8 * half;
+          const floatx4 h0 = *reinterpret_cast<const floatx4*>(q), h1 = *reinterpret_cast<const floatx4*>(q + 4);
+          const floatx4 g0 = *reinterpret_cast<const floatx4*>(q + 16), g1 = *reinterpret_cast<const floatx4*>(q + 20);
+          const half8_t first = *reinterpret_cast<const half8_t*>(ost + buf * 2048 + prow * 128 + (pw * 16 + 8 * half) * 2);
+          *reinterpret_cast<half8_t*>(cp0) = first;
+          half8_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = (half_t)((h0[j] + bh[j]) * gelu_fast(g0[j] + bg[j]));
+            o[j + 4] = (half_t)((h1[j] + bh[j + 4]) * gelu_fast(g1[j] + bg[j + 4]));
+          }
+          *reinterpret_cast<half8_t*>(cp0 + 16) = o;
+          cp0 += cstep;
         }
       }
     } else {
