@@ -469,26 +469,36 @@ static int env_int(const char* name, int dflt) { return md_env_int(name, dflt); 
 #include "gemm_pp.h"
 #include "gemm_ws.h"
 
-template <int KS, int CB, bool RES, bool RA>
+template <int KS, int CB, int TPR, bool RES, bool RA>
 static void launch_ws_variant(const WsParams& p, hipStream_t stream) {
-  using Cfg = WsCfg<KS, CB>;
-  md_ensure_dynamic_lds<wsgemm_kernel<KS, CB, RES, RA>>(Cfg::SMEM);
-  hipLaunchKernelGGL((wsgemm_kernel<KS, CB, RES, RA>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+  using Cfg = WsCfg<KS, CB, TPR>;
+  md_ensure_dynamic_lds<wsgemm_kernel<KS, CB, TPR, RES, RA>>(Cfg::SMEM);
+  hipLaunchKernelGGL((wsgemm_kernel<KS, CB, TPR, RES, RA>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+}
+
+template <int KS, int CB, int TPR>
+static void launch_ws_tpr(const WsParams& p, hipStream_t stream) {
+  if (p.residual && p.rowadd) launch_ws_variant<KS, CB, TPR, true, true>(p, stream);
+  else if (p.residual) launch_ws_variant<KS, CB, TPR, true, false>(p, stream);
+  else if (p.rowadd) launch_ws_variant<KS, CB, TPR, false, true>(p, stream);
+  else launch_ws_variant<KS, CB, TPR, false, false>(p, stream);
 }
 
 template <int KS, int CB>
 static void launch_ws(const GemmParams& g, hipStream_t stream) {
-  using Cfg = WsCfg<KS, CB>;
+  constexpr int GC = 64 * CB;
   WsParams p;
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = g.residual; p.rowadd = g.rowadd;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr; p.ldra = g.ldra; p.M = g.M; p.N = g.N; p.rows_per_group = g.rows_per_group;
-  p.groups = g.N / Cfg::GC;
+  p.groups = g.N / GC;
   p.spx = 32 / p.groups;
   p.streams = 8 * p.spx;
-  if (g.residual && g.rowadd) launch_ws_variant<KS, CB, true, true>(p, stream);
-  else if (g.residual) launch_ws_variant<KS, CB, true, false>(p, stream);
-  else if (g.rowadd) launch_ws_variant<KS, CB, false, true>(p, stream);
-  else launch_ws_variant<KS, CB, false, false>(p, stream);
+  // one tile per barrier round (deepest DMA ring) when the launch streams A from HBM once and sits on the store path (one column
+  // group); two tiles per round when several groups share A through L2 and the tile time is barrier / latency bound
+  static const int tpr = env_int("MD_GEMM_WS_TPR", 0);           // 0: automatic, 1 / 2: forced
+  const bool two = tpr == 2 || (tpr == 0 && p.groups > 1);
+  if (two) launch_ws_tpr<KS, CB, 2>(p, stream);
+  else launch_ws_tpr<KS, CB, 1>(p, stream);
 }
 
 // GEGLU flavour of the streaming kernel: K = 320, packed N % 256 == 0 (128 output columns per workgroup), long M
@@ -500,15 +510,23 @@ static bool ws_geglu_eligible(const GemmParams& p) {
 }
 
 static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
-  using Cfg = WsCfg<10, 4>;
   WsParams p;
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = nullptr; p.rowadd = nullptr;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = 0; p.ldra = 0; p.M = g.M; p.N = g.N; p.rows_per_group = 1;
-  p.groups = g.N / Cfg::GC;
+  p.groups = g.N / 256;
   p.spx = 32 / p.groups;
   p.streams = 8 * p.spx;
-  md_ensure_dynamic_lds<wsgemm_kernel<10, 4, false, false, true>>(Cfg::SMEM);
-  hipLaunchKernelGGL((wsgemm_kernel<10, 4, false, false, true>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+  // the GELU arithmetic, not the barrier rounds, bounds a GEGLU tile (VALU of compute + store waves on the same SIMDs): one
+  // tile per round measured 2 % faster than two
+  static const int tpr = env_int("MD_GEMM_WS_TPR", 0);
+  constexpr int smem1 = WsCfg<10, 4, 1>::SMEM, smem2 = WsCfg<10, 4, 2>::SMEM;
+  if (tpr != 2) {
+    md_ensure_dynamic_lds<wsgemm_kernel<10, 4, 1, false, false, true>>(smem1);
+    hipLaunchKernelGGL((wsgemm_kernel<10, 4, 1, false, false, true>), dim3(256), dim3(512), smem1, stream, p);
+  } else {
+    md_ensure_dynamic_lds<wsgemm_kernel<10, 4, 2, false, false, true>>(smem2);
+    hipLaunchKernelGGL((wsgemm_kernel<10, 4, 2, false, false, true>), dim3(256), dim3(512), smem2, stream, p);
+  }
 }
 
 // W-stationary streaming kernel (gemm_ws.h): plain epilogues, K = 320 (N % 320 == 0) or K = 640 (N % 128 == 0), long M.
