@@ -54,8 +54,10 @@ __device__ __forceinline__ float a2_xhalf_max(float x) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int D, int NST, int QT, int WPS>
-__global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
+template <int D, int NST, int QT, int WPS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
+  // NW waves per workgroup, 32*QT queries each: every K / V^T tile a workgroup DMAs into LDS is shared by all NW waves, so a
+  // 16-wave workgroup (one per CU at 4 waves per SIMD) fetches and issues a quarter of the DMA pieces of four 4-wave ones
   constexpr int KS = (D + 15) / 16;            // k-steps of Q K^T
   constexpr bool ONES = (D % 32) != 0;         // room for the ones row in the last O^T tile
   constexpr int DVT = (D + 31) / 32;           // 32-row tiles of O^T
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   // XCD-aware mapping: workgroup id L runs on XCD L % 8 (observed dispatch order, speed only).  All q-blocks of one
   // (batch, head) pair go to ONE XCD so that its K / V^T tiles are fetched into a single private L2 instead of all
   // eight (measured: 8x the algorithmic K/V bytes at the fabric otherwise).
-  const int nqb = (p.Lq + 128 * QT - 1) / (128 * QT);
+  const int nqb = (p.Lq + 32 * NW * QT - 1) / (32 * NW * QT);
   int pair, qblk;
   {
     const int L = blockIdx.x, npair = p.B * p.H;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   }
   const int b = pair / p.H, h = pair - b * p.H;
   const int kb = p.kv_index ? p.kv_index[b] : b;
-  const int q0 = qblk * (128 * QT) + wave * (32 * QT);
+  const int q0 = qblk * (32 * NW * QT) + wave * (32 * QT);
   const int lk8 = (p.Lk + 7) & ~7;
 
   const half_t* Kb = p.K + (size_t)kb * p.kv_stride * p.ldk + h * D;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 
   // constant rows of every V^T stage: ones in row D (softmax denominator), zeros in the rest of the padding
   if (D % 32 != 0) {
-    for (int i = tid; i < NST * (DVT * 32 - D) * 8; i += 256) {
+    for (int i = tid; i < NST * (DVT * 32 - D) * 8; i += 64 * NW) {
       const int st = i / ((DVT * 32 - D) * 8), rem = i % ((DVT * 32 - D) * 8);
       const int row = D + rem / 8, slot = rem % 8;
       const half_t v = row == D ? (half_t)1.0f : (half_t)0.0f;
@@ -137,16 +139,16 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     }
   }
 
-  // ---- DMA: instruction q of a tile (q < NKI: K image, else V^T image) is issued by wave q % 4
-  const int n_mine = (NI - wave + 3) / 4;
+  // ---- DMA: instruction q of a tile (q < NKI: K image, else V^T image) is issued by wave q % NW
+  const int n_mine = wave < NI ? (NI - wave + NW - 1) / NW : 0;
   // per-lane source of tile 0 and the per-tile byte step (K: 64 rows down, V^T: 64 keys = 128 bytes to the right), so that a
   // full tile costs one 64-bit add per DMA; only the ragged last tile recomputes clamped addresses
-  constexpr int NQ = (NI + 3) / 4;
+  constexpr int NQ = (NI + NW - 1) / NW;
   const char* src0[NQ];
   long step[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
-    const int q = qi * 4 + wave;
+    const int q = qi * NW + wave;
     src0[qi] = reinterpret_cast<const char*>(Kb);
     step[qi] = 0;
     if (q < NKI) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     if (j0 + A2_KT <= p.Lk) {
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        const int q = qi * 4 + wave;
+        const int q = qi * NW + wave;
         if (q < NI)
           __builtin_amdgcn_global_load_lds((gptr_t)(src0[qi] + it_ * step[qi]), (lptr_t)(sb + (q < NKI ? q * 1024 : KBYTES + (q - NKI) * 1024)), 16, 0, 0);
       }
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
-      const int q = qi * 4 + wave;
+      const int q = qi * NW + wave;
       if (q < NKI) {
         const int o = q * 1024 + lane * 16;
         const int row = o / KROWB, cb = o - row * KROWB;
@@ -235,6 +237,28 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[u][sub][r] = 0.f;
+#ifdef A2_QKPRE
+    {
+      // all K fragments of the tile in flight before the first MFMA; the two 32-key chains alternate
+      half8_t kfr[2][KS];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const char* kp = ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2;
+          if (FOLD && k == KS - 1) kp = hi ? smem + CONST_OFF + sub * 32 * KROWB : kp;
+          kfr[sub][k] = *reinterpret_cast<const half8_t*>(kp);
+        }
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int u = 0; u < QT; ++u) s[u][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[sub][k], qf[u][k], s[u][sub], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * KS * QT, 0);
+    }
+#else
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -252,6 +276,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 #endif
       }
     }
+#endif
     // register r of sub-tile `sub` in lane half `hi` holds key j0 + sub*32 + 16*(r>>3) + 8*hi + (r&7)
     if (j0 + A2_KT > p.Lk) {
 #pragma unroll
@@ -373,9 +398,13 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
   }
 }
 
-template <int D, int QT>
+template <int D, int QT, int NW = 4>
 static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
+#ifdef A2_NST
+  constexpr int NST = A2_NST;
+#else
   constexpr int NST = 2;   // same-box A/B on MI355X: a 2-deep ring beats 3-deep by ~3 % at D = 40 (less LDS, same overlap)
+#endif
   // occupancy targets that fit without spilling: D <= 40 -> 4 waves/SIMD (<= 128 registers), D <= 80 -> 3 (<= 168)
 #if defined(A2_WPS6)
   constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 6 : (D <= 80 ? 3 : 1));
@@ -386,9 +415,9 @@ static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
 #endif
   constexpr int DVT = (D + 31) / 32;
   constexpr int smem = NST * (A2_KT * D * 2 + DVT * 32 * 128) + ((D % 16) == 8 ? 32 * D * 2 + 16 : 0);   // + the FOLD constants
-  md_ensure_dynamic_lds<attn2_kernel<D, NST, QT, WPS>>(smem);
-  dim3 grid(cdiv(p.Lq, 128 * QT) * p.H * p.B);
-  hipLaunchKernelGGL((attn2_kernel<D, NST, QT, WPS>), grid, dim3(256), smem, stream, p);
+  md_ensure_dynamic_lds<attn2_kernel<D, NST, QT, WPS, NW>>(smem);
+  dim3 grid(cdiv(p.Lq, 32 * NW * QT) * p.H * p.B);
+  hipLaunchKernelGGL((attn2_kernel<D, NST, QT, WPS, NW>), grid, dim3(64 * NW), smem, stream, p);
   MD_CHECK_LAUNCH("md_attention_fwd");
   return MD_OK;
 }
@@ -401,6 +430,12 @@ static int launch_attn2(const AttnParams& p, hipStream_t stream) {
   if constexpr (D <= 80) {
     const bool two = qt_env == 2;   // measured slower on MI355X (1 wave/SIMD, the compiler does not interleave the chains)
     if (two) return launch_attn2_qt<D, 2>(p, stream);
+  }
+  if constexpr (D <= 40) {
+    // long self-attention: wider workgroups share each K / V^T tile between more waves (MD_ATTN_NW = 4 | 8 | 16)
+    static const int nw = md_env_int("MD_ATTN_NW", 4);
+    if (nw == 16 && p.Lq >= 2048) return launch_attn2_qt<D, 1, 16>(p, stream);
+    if (nw == 8 && p.Lq >= 1024) return launch_attn2_qt<D, 1, 8>(p, stream);
   }
   return launch_attn2_qt<D, 1>(p, stream);
 }
