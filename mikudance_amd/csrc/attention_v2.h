@@ -237,9 +237,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[u][sub][r] = 0.f;
-#ifdef A2_QKPRE
-    {
-      // all K fragments of the tile in flight before the first MFMA; the two 32-key chains alternate
+    if constexpr (D <= 40) {
+      // all K fragments of the tile in flight before the first MFMA (one LDS latency per tile instead of three) and the two
+      // 32-key accumulation chains alternate: +1 % at d = 40 on MI355X (same-box, with 8-wave workgroups); 24 more registers,
+      // which the d = 80 / 160 flavours do not have
       half8_t kfr[2][KS];
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
@@ -257,8 +258,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
           for (int u = 0; u < QT; ++u) s[u][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[sub][k], qf[u][k], s[u][sub], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * KS * QT, 0);
-    }
-#else
+    } else {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
 #endif
       }
     }
-#endif
+    }
     // register r of sub-tile `sub` in lane half `hi` holds key j0 + sub*32 + 16*(r>>3) + 8*hi + (r&7)
     if (j0 + A2_KT > p.Lk) {
 #pragma unroll
@@ -432,8 +432,9 @@ static int launch_attn2(const AttnParams& p, hipStream_t stream) {
     if (two) return launch_attn2_qt<D, 2>(p, stream);
   }
   if constexpr (D <= 40) {
-    // long self-attention: wider workgroups share each K / V^T tile between more waves (MD_ATTN_NW = 4 | 8 | 16)
-    static const int nw = md_env_int("MD_ATTN_NW", 4);
+    // long self-attention: wider workgroups share each K / V^T tile between more waves (MD_ATTN_NW = 4 | 8 | 16).  Same-box on
+    // MI355X at L = 9216: 8 waves 802-810 TFLOP/s, 16 waves 803, 4 waves 782 (two workgroups per CU still run out of phase)
+    static const int nw = md_env_int("MD_ATTN_NW", 8);
     if (nw == 16 && p.Lq >= 2048) return launch_attn2_qt<D, 1, 16>(p, stream);
     if (nw == 8 && p.Lq >= 1024) return launch_attn2_qt<D, 1, 8>(p, stream);
   }

@@ -516,17 +516,10 @@ static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
   p.groups = g.N / 256;
   p.spx = 32 / p.groups;
   p.streams = 8 * p.spx;
-  // the GELU arithmetic, not the barrier rounds, bounds a GEGLU tile (VALU of compute + store waves on the same SIMDs): one
-  // tile per round measured 2 % faster than two
-  static const int tpr = env_int("MD_GEMM_WS_TPR", 0);
-  constexpr int smem1 = WsCfg<10, 4, 1>::SMEM, smem2 = WsCfg<10, 4, 2>::SMEM;
-  if (tpr != 2) {
-    md_ensure_dynamic_lds<wsgemm_kernel<10, 4, 1, false, false, true>>(smem1);
-    hipLaunchKernelGGL((wsgemm_kernel<10, 4, 1, false, false, true>), dim3(256), dim3(512), smem1, stream, p);
-  } else {
-    md_ensure_dynamic_lds<wsgemm_kernel<10, 4, 2, false, false, true>>(smem2);
-    hipLaunchKernelGGL((wsgemm_kernel<10, 4, 2, false, false, true>), dim3(256), dim3(512), smem2, stream, p);
-  }
+  // the GELU arithmetic (shared by the four memory waves), not the barrier rounds, bounds a GEGLU tile: one tile per round
+  constexpr int smem = WsCfg<10, 4, 1>::SMEM;
+  md_ensure_dynamic_lds<wsgemm_kernel<10, 4, 1, false, false, true>>(smem);
+  hipLaunchKernelGGL((wsgemm_kernel<10, 4, 1, false, false, true>), dim3(256), dim3(512), smem, stream, p);
 }
 
 // W-stationary streaming kernel (gemm_ws.h): plain epilogues, K = 320 (N % 320 == 0) or K = 640 (N % 128 == 0), long M.

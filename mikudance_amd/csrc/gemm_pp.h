@@ -413,7 +413,7 @@ static void launch_pp(GemmParams& p, hipStream_t stream) {
 // of the workgroup; ring slot g & 3; barrier / vmcnt bookkeeping exactly as in gemm_pp_kernel with T in place of nk.
 __global__ __launch_bounds__(512, 2) void gemm_ppg_kernel(GemmParams p) {
   constexpr int BK = 32, MI = 2, NJ = 4;
-  constexpr int BM = 256, BN = 256, NW = 8;
+  constexpr int BM = 256, BN = 256;
   constexpr int ROWB = 64, RPI = 16;
   constexpr int IPA = 2, IPB = 2, G = IPA + IPB;
   constexpr int OPA = BM * ROWB, STAGE = (BM + BN) * ROWB;

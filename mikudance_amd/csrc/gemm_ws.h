@@ -26,7 +26,8 @@
 //     ONE s_barrier per round hands the stages round.  A raw s_barrier does not wait for a wave's LDS stores (gfx950 has the
 //     back-off barrier, the compiler adds no s_waitcnt), so the compute waves drain lgkmcnt before it.
 //   * TPR = 1 (deepest DMA ring) for the single-group launches (N = 320: streams A from HBM, sits on the store path) and for
-//     GEGLU (bound by the GELU VALU work that compute and store waves do on the same SIMDs); TPR = 2 for the multi-group plain
+//     GEGLU (bound by the GELU VALU work, which the four MEMORY waves share, one per SIMD, so that the MFMA-issuing waves
+//     carry none of it); TPR = 2 for the multi-group plain
 //     launches, whose A comes out of L2: two tiles per barrier round let the staging stores of the first tile and the fragment
 //     latency of the second overlap the MFMAs (K = 640: +6-10 %, K = 320 N = 960: +2 %).
 //   * a launch with G = N / group column groups runs G workgroups side by side on the same row stream inside one XCD, so
@@ -64,10 +65,9 @@ struct WsCfg {
   static constexpr int STAGE = TR * K * 2;        // bytes per A tile
   static constexpr int RSTAGE = TPR * STAGE;      // ... per round
   static constexpr bool GEGLU_CFG = CB == 4;      // the GEGLU flavour is the only one with 4 column blocks per wave
-  static constexpr int CS_LD = (GEGLU_CFG ? GC / 2 : GC) + 4;   // fp32 staging pitch (floats): rows shift by 4 banks; GEGLU stages
-                                                  // only column pair 1 (h1 | g1: 32 floats per compute wave)
+  static constexpr int CS_LD = GC + 4;            // fp32 staging pitch (floats): rows shift by 4 banks
   static constexpr int CSTAGE = TR * CS_LD * 4;   // one staging tile; 2 * TPR of them (double buffered rounds)
-  static constexpr int OSTAGE = GEGLU_CFG ? 2 * TPR * 2048 : 0;   // GEGLU: fp16 outputs finished by the compute waves (2 KiB per tile)
+  static constexpr int OSTAGE = GEGLU_CFG ? 2 * 2048 : 0;   // GEGLU: fp16 pieces finished by the loader waves, shipped by the store waves
   static constexpr int NR_FIT = (160 * 1024 - 2 * TPR * CSTAGE - OSTAGE) / RSTAGE;
   static constexpr int NR = NR_FIT > 12 ? 12 : NR_FIT;       // ring depth in rounds
   static constexpr int DPT = STAGE / 1024;        // DMA wave-instructions per tile
@@ -86,16 +86,34 @@ __device__ __forceinline__ int ws_swz(int row) {
   return CPR == 40 ? ((row >> 1) & 7) : (row & 15);
 }
 
+// GEGLU flavour: one 16-byte output piece = 8 columns of (h + b_h) * gelu_erf(g + b_g) from the fp32 staging tile.
+struct WsGegluPiece {
+  int row, hcol;            // staging row, staging column of h (g sits 32 columns further)
+  float bh[8], bg[8];
+};
+__device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, const WsGegluPiece& q) {
+  const float* s = cs + q.row * cs_ld + q.hcol;
+  const floatx4 h0 = *reinterpret_cast<const floatx4*>(s), h1 = *reinterpret_cast<const floatx4*>(s + 4);
+  const floatx4 g0 = *reinterpret_cast<const floatx4*>(s + 32), g1 = *reinterpret_cast<const floatx4*>(s + 36);
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (half_t)((h0[j] + q.bh[j]) * gelu_fast(g0[j] + q.bg[j]));
+    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gelu_fast(g1[j] + q.bg[j + 4]));
+  }
+  return o;
+}
+
 template <int KS, int CB, int TPR, bool RES, bool RA, bool GEGLU = false>
 __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
-  static_assert(!GEGLU || (CB == 4 && !RES && !RA), "GEGLU: 2 h + 2 g column blocks per compute wave, bias only");
+  static_assert(!GEGLU || (CB == 4 && TPR == 1 && !RES && !RA), "GEGLU: 2 h + 2 g column blocks per compute wave, one tile per round, bias only");
   using Cfg = WsCfg<KS, CB, TPR>;
   constexpr int K = Cfg::K, CPR = Cfg::CPR, GC = Cfg::GC, TR = Cfg::TR, STAGE = Cfg::STAGE, RSTAGE = Cfg::RSTAGE, NR = Cfg::NR,
                 CS_LD = Cfg::CS_LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
   float* cst = reinterpret_cast<float*>(smem + NR * RSTAGE);       // staging tile (round parity, tile u): index (r & 1) * TPR + u
-  char* ost = smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE;          // GEGLU: fp16 pieces, same indexing, 2 KiB each
+  char* ost = smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE;          // GEGLU: 2 x 2 KiB of finished fp16 pieces, loader -> store waves
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // workgroup -> (XCD, column group, row stream): the G groups of one row stream share an XCD (blockIdx % 8)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -107,6 +125,27 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   if (my_tiles == 0) return;
   const int rounds = (my_tiles + TPR - 1) / TPR;                  // barriers b_0 .. b_rounds
   const int n0 = grp * GC;
+  // GEGLU (FeedForward net.0, reference src/models/attention.py:152-157 / diffusers FeedForward): the weight rows are packed in
+  // blocks of 32 h rows then 32 g rows (packing.geglu_weight), so staging columns [64w, 64w+32) hold h and [64w+32, 64w+64) hold
+  // g of output columns [32w, 32w+32) of this workgroup; out = (h + b_h) * gelu_erf(g + b_g), one rounding, 16-byte stores into
+  // the [M][N/2] output.  The GELU arithmetic (two transcendentals + ~14 VALU per output) is the longest job of a tile, so all
+  // FOUR memory waves (one per SIMD) share it: piece id = (wave - 4) * 64 + lane of the tile's 256 pieces.  The store waves write
+  // theirs to global memory; the loader waves (whose vmcnt must see nothing but their DMAs) park theirs in LDS and the store
+  // waves ship them one round later.  One extra barrier at the end drains that pipeline stage.  (Same-box, in the denoising
+  // loop: 109 ms per clip against 118 ms with half of the GELU in the compute waves, although the two tie on random inputs.)
+  WsGegluPiece gp = {};
+  if constexpr (GEGLU) {
+    if (wave >= 4) {
+      const int id = (wave - 4) * 64 + lane;
+      gp.row = id / (GC / 16);
+      const int oc = (id % (GC / 16)) * 8;
+      gp.hcol = 64 * (oc >> 5) + (oc & 31);
+      const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol + 32) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gp.bh[j] = (float)b0[j], gp.bg[j] = (float)b1[j];
+    }
+  }
 
   if (wave < 4) {
     // ------------------------------------------------------------------------------------------------ compute waves
@@ -120,18 +159,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     }
     const int row = lane & 15, kq = lane >> 4;
     const int rbase = row * CPR, sw = ws_swz<CPR>(row);
-    // GEGLU: the exact-erf GELU is split between the waves that have slack: every compute wave finishes column pair 0 (its h
-    // block 0 and g block 0: 4 outputs per lane, fp16 straight into LDS), the two store waves finish pair 1 and ship both
-    float gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (GEGLU) {
-      if (p.bias) {
-        const half4_t b0 = *reinterpret_cast<const half4_t*>(p.bias + n0 + wave * 64 + 4 * kq);
-        const half4_t b1 = *reinterpret_cast<const half4_t*>(p.bias + n0 + wave * 64 + 32 + 4 * kq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gb[r] = (float)b0[r], gb[4 + r] = (float)b1[r];
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): weights (and bias) are in registers before the loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): weights are in registers before the loop
     constexpr int PD = Cfg::PD;
     constexpr int SWB = CPR == 40 ? 3 : 4, P = (1 << SWB) / 4;
     auto compute_tile = [&](const char* st, int buf) {
@@ -158,20 +186,9 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                       //     ahead of that step's CB MFMAs
       }
       // acc[cb][r] = C[m = row][n = wave*16CB + cb*16 + 4*kq + r]
-      if constexpr (GEGLU) {
-        // blocks 0, 1 = h columns 0-15, 16-31 of this wave's 32 outputs, blocks 2, 3 = the matching g columns
-        half4_t o;
+      float* cs = cst + buf * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc[0][r] + gb[r]) * gelu_fast(acc[2][r] + gb[4 + r]));
-        *reinterpret_cast<half4_t*>(ost + buf * 2048 + row * 128 + (wave * 16 + 4 * kq) * 2) = o;
-        float* cs = cst + buf * (TR * CS_LD) + row * CS_LD + wave * 32 + 4 * kq;
-        *reinterpret_cast<floatx4*>(cs) = acc[1];
-        *reinterpret_cast<floatx4*>(cs + 16) = acc[3];
-      } else {
-        float* cs = cst + buf * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
-      }
+      for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
     };
     for (int r = 0; r < rounds; ++r) {
       __builtin_amdgcn_s_barrier();                 // b_r: round r has landed; the staging tiles of parity r & 1 are free
@@ -182,6 +199,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging stores WRITTEN before the hand-over barrier
     }
     __builtin_amdgcn_s_barrier();                   // b_rounds
+    if constexpr (GEGLU) __builtin_amdgcn_s_barrier();   // b_{rounds + 1}
   } else if (wave < 6) {
     // ------------------------------------------------------------------------------------------------ loader waves
     const int lw = wave - 4;
@@ -207,6 +225,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         }
       }
     };
+    if constexpr (GEGLU) __builtin_amdgcn_s_waitcnt(0x0F70);      // the bias loads above: nothing but DMAs may be counted below
     const int pre = rounds < NR - 1 ? rounds : NR - 1;
     for (int q = 0; q < pre; ++q) issue_round(q);
     for (int r = 0; r < rounds; ++r) {
@@ -216,50 +235,39 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();                 // also: the compute waves are done with round r-1 -> its stage is free
       if (r + NR - 1 < rounds) issue_round(r + NR - 1);   // into stage (r - 1) % NR
+      if constexpr (GEGLU) {
+        if (r >= 1) {                               // this wave's piece of tile r-1 -> LDS (shipped by a store wave after b_{r+1})
+          const half8_t o = ws_geglu_piece(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          *reinterpret_cast<half8_t*>(ost + ((r - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
     }
     __builtin_amdgcn_s_barrier();                   // b_rounds
+    if constexpr (GEGLU) {
+      const half8_t o = ws_geglu_piece(cst + ((rounds - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+      *reinterpret_cast<half8_t*>(ost + ((rounds - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // b_{rounds + 1}
+    }
   } else {
     // ------------------------------------------------------------------------------------------------ store waves
     if constexpr (GEGLU) {
-      // FeedForward net.0 (GEGLU, reference src/models/attention.py:152-157 / diffusers FeedForward): the weight rows are packed
-      // in blocks of 32 h rows then 32 g rows (packing.geglu_weight), so compute wave w owns exactly one block = output columns
-      // [32w, 32w+32) of this workgroup's 128.  out = (h + b_h) * gelu_erf(g + b_g), one rounding, 16-byte stores into the
-      // [M][N/2] output.  Per tile this lane ships TWO pieces of its row: columns 32w + 8*half (pair 0, finished by compute wave w,
-      // fp16 in LDS) and 32w + 16 + 8*half (pair 1: from the fp32 staging tile, GELU done here).
       constexpr int OC = GC / 2;
-      const int sid = (wave - 6) * 64 + lane;                         // 0..127 = 16 rows x 4 waves x 2 halves
-      const int prow = sid >> 3, pw = (sid >> 1) & 3, half = sid & 1;
-      float bh[8], bg[8];
-      {
-        const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pw * 64 + 16 + 8 * half) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pw * 64 + 48 + 8 * half) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bh[j] = (float)b0[j], bg[j] = (float)b1[j];
-      }
+      const int sw2 = wave - 6;                                          // 0 / 1: ships the pieces of loader wave sw2 as well
+      const int id_own = (wave - 4) * 64 + lane, id_ld = sw2 * 64 + lane;
       const size_t cstep = (size_t)p.streams * TR * p.ldc;
-      half_t* cp0 = p.C + (size_t)(stream * TR + prow) * p.ldc + grp * OC + pw * 32 + 8 * half;
-      for (int r = 0; r <= rounds; ++r) {
+      half_t* cp_own = p.C + (size_t)(stream * TR + id_own / (OC / 8)) * p.ldc + grp * OC + (id_own % (OC / 8)) * 8;
+      half_t* cp_ld = p.C + (size_t)(stream * TR + id_ld / (OC / 8)) * p.ldc + grp * OC + (id_ld % (OC / 8)) * 8;
+      for (int r = 0; r <= rounds + 1; ++r) {
         __builtin_amdgcn_s_barrier();                                   // b_r
-        if (r >= 1) {
-#pragma unroll
-          for (int u = 0; u < TPR; ++u) {
-            if ((r - 1) * TPR + u < my_tiles) {
-              const int buf = ((r - 1) & 1) * TPR + u;
-              const float* q = cst + buf * (TR * CS_LD) + prow * CS_LD + pw * 32 + 8 * half;
-              const floatx4 h0 = *reinterpret_cast<const floatx4*>(q), h1 = *reinterpret_cast<const floatx4*>(q + 4);
-              const floatx4 g0 = *reinterpret_cast<const floatx4*>(q + 16), g1 = *reinterpret_cast<const floatx4*>(q + 20);
-              const half8_t first = *reinterpret_cast<const half8_t*>(ost + buf * 2048 + prow * 128 + (pw * 16 + 8 * half) * 2);
-              *reinterpret_cast<half8_t*>(cp0) = first;
-              half8_t o;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                o[j] = (half_t)((h0[j] + bh[j]) * gelu_fast(g0[j] + bg[j]));
-                o[j + 4] = (half_t)((h1[j] + bh[j + 4]) * gelu_fast(g1[j] + bg[j + 4]));
-              }
-              *reinterpret_cast<half8_t*>(cp0 + 16) = o;
-              cp0 += cstep;
-            }
-          }
+        if (r >= 2) {                                                   // loader pieces of tile r-2, parked in LDS during round r-1
+          *reinterpret_cast<half8_t*>(cp_ld) = *reinterpret_cast<const half8_t*>(ost + ((r - 2) & 1) * 2048 + id_ld * 16);
+          cp_ld += cstep;
+        }
+        if (r >= 1 && r <= rounds) {                                    // own piece of tile r-1
+          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          cp_own += cstep;
         }
       }
     } else {

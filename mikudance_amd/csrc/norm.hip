@@ -7,23 +7,46 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
+// Statistics are the one-sweep sums of (x - k) and (x - k)^2 in fp32, k = the group's mean over PIXEL 0 of the image (its cpg
+// channels): a pilot of the group mean, so the sums stay O(n * sigma) and var = E[(x-k)^2] - E[x-k]^2 does not cancel when
+// |mean| >> sigma (the plain E[x^2] - mean^2 loses the variance at |mean| / sigma ~ 100 in fp32).  Both kernels derive k with
+// this one function, so it is bit-identical on the two sides.  kc: >= C floats of scratch LDS, kg: >= G floats.
+__device__ __forceinline__ void gn_pilot(const half_t* __restrict__ ximg, int C, int G, float* kc, float* kg) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) kc[c] = (float)ximg[c];
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += kc[c];
+    kg[g] = a / (float)cpg;
+  }
+  __syncthreads();
+}
+
 // Thread (cc, r): channel chunk cc (8 channels), row lane r.  A block owns `slab` consecutive pixels of one image.
 __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int R, int slab, int nslab) {
-  extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq
+  extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq (first: pilot scratch)
+  __shared__ float kg[64];
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
   const int b = blockIdx.y, sl = blockIdx.x;
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
-  float s[8], q[8];
+  const int cpg = C / G;
+  gn_pilot(x + (size_t)b * HW * C, C, G, sh, kg);
+  float s[8], q[8], k[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  for (int e = 0; e < 8; ++e) {
+    s[e] = q[e] = 0.f;
+    k[e] = kg[(cc * 8 + e) / cpg];
+  }
+  __syncthreads();               // the pilot scratch in sh[] is re-used for the sums below
   const half_t* base = x + (size_t)b * HW * C + cc * 8;
 #pragma unroll 4
   for (int p = p0 + r; p < p1; p += R) {
     const half8_t v = *reinterpret_cast<const half8_t*>(base + (size_t)p * C);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float f = (float)v[e];
+      const float f = (float)v[e] - k[e];
       s[e] += f;
       q[e] += f * f;
     }
@@ -36,7 +59,6 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     sq[r * C + cc * 8 + e] = q[e];
   }
   __syncthreads();
-  const int cpg = C / G;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     float a = 0.f, c2 = 0.f;
     for (int rr = 0; rr < R; ++rr)
@@ -52,11 +74,13 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
 
 __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ part, const half_t* __restrict__ gamma,
                                 const half_t* __restrict__ beta, int HW, int C, int G, int R, int slab, int nslab, float eps, int silu) {
-  __shared__ float mean_s[64], rstd_s[64];
+  __shared__ float mean_s[64], rstd_s[64], kg[64];
+  extern __shared__ float kc[];  // [C] pilot scratch
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
   const int b = blockIdx.y, sl = blockIdx.x;
   const int cpg = C / G;
+  gn_pilot(x + (size_t)b * HW * C, C, G, kc, kg);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     float a = 0.f, c2 = 0.f;
     const float* pp = part + ((size_t)b * nslab * G + g) * 2;
@@ -65,9 +89,9 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
       c2 += pp[(size_t)k * G * 2 + 1];
     }
     const float n = (float)HW * (float)cpg;
-    const float mu = a / n;
+    const float mu = a / n;                               // mean of x - k
     const float var = fmaxf(c2 / n - mu * mu, 0.f);
-    mean_s[g] = mu;
+    mean_s[g] = kg[g] + mu;
     rstd_s[g] = rsqrtf(var + eps);
   }
   __syncthreads();
@@ -117,7 +141,7 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
   dim3 grid(nslab, B), block(cch * R);
   const size_t sh = (size_t)2 * R * C * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, HW, C, G, R, slab, nslab);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const half_t*)gamma,
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, (size_t)C * sizeof(float), (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const half_t*)gamma,
                      (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu);
   MD_CHECK_LAUNCH("md_groupnorm");
   return MD_OK;
@@ -251,6 +275,8 @@ __global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __res
   const int cc = threadIdx.x & 7, r = threadIdx.x >> 3;
   const int b = blockIdx.y, c0 = blockIdx.x * 64 + cc * 8;
   const half_t* xb = x + (size_t)b * HW * C + c0;
+  // sums of (x - k), (x - k)^2 with k = the channel's value at pixel 0 (a pilot of its mean: no cancellation when |mean| >> sigma)
+  const half8_t k8 = *reinterpret_cast<const half8_t*>(xb);
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __res
     const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * C);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float f = (float)v[e];
+      const float f = (float)v[e] - (float)k8[e];
       s[e] += f;
       q[e] += f * f;
     }
@@ -275,8 +301,8 @@ __global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __res
       a += ss[rr][threadIdx.x];
       c2 += sq[rr][threadIdx.x];
     }
-    const float mu = a / (float)HW;
-    mean_s[threadIdx.x] = mu;
+    const float mu = a / (float)HW;                     // mean of x - k
+    mean_s[threadIdx.x] = (float)x[(size_t)b * HW * C + blockIdx.x * 64 + threadIdx.x] + mu;
     rstd_s[threadIdx.x] = rsqrtf(fmaxf(c2 / (float)HW - mu * mu, 0.f) + eps);
   }
   __syncthreads();

@@ -22,7 +22,10 @@ struct TemporalParams {
 // frames are first staged in LDS with fully coalesced 16-byte loads (every K/V byte is read from HBM exactly once and
 // then re-used by the F query lanes from LDS: ds_read_b128, conflict free because the HG head-lanes sit D*2 bytes
 // apart and the F frame-lanes broadcast).
-template <int FMAX>
+// NCH = D / 8 when the head dim is one of the UNet's (40 / 80 / 160): the lane's whole query row is then fetched into registers
+// BEFORE the K/V staging is issued, so its HBM latency hides behind the DMA instead of being paid once per 8-column chunk
+// inside the score loop (NCH = 0: any D, query chunks loaded in the loop).
+template <int FMAX, int NCH>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -38,6 +41,20 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   // maximum memory-level parallelism) and waits once.  Each region is padded to a whole number of 1-KiB DMA rows.
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // this lane's (pixel, head, query frame); lanes past the last pixel keep a valid address and are retired after the barrier
+  const int hl = t % p.HG;
+  const int i = (t / p.HG) % p.F;
+  const int pl = t / (p.HG * p.F);
+  const long gpq = pg + pl;
+  const bool live = pl < p.PB && gpq < npix;
+  const long gpc = min(gpq, npix - 1);
+  const size_t qrow = ((size_t)(gpc / p.HW) * p.F + i) * p.HW + (size_t)(gpc % p.HW);
+  const half_t* qp = p.Q + qrow * p.ldq + col0 + hl * p.D;
+  half8_t qreg[NCH > 0 ? NCH : 1];
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) qreg[c] = *reinterpret_cast<const half8_t*>(qp + c * 8);
+  }
   const int nchunk = p.F * p.PB * cw8;
   const int region = ((nchunk * 16 + 1023) >> 10) << 10;
   half_t* Ks = reinterpret_cast<half_t*>(smem);
@@ -57,19 +74,12 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int hl = t % p.HG;
-  const int i = (t / p.HG) % p.F;
-  const int pl = t / (p.HG * p.F);
-  const long gp = pg + pl;
-  if (pl >= p.PB || gp >= npix) return;
-  const int b = (int)(gp / p.HW), pix = (int)(gp % p.HW);
-  const size_t qrow = ((size_t)b * p.F + i) * p.HW + pix;
-  const half_t* qp = p.Q + qrow * p.ldq + col0 + hl * p.D;
+  if (!live) return;
   half_t* op = p.O + qrow * p.ldo + col0 + hl * p.D;
   const half_t* kp = Ks + (size_t)pl * CW + hl * p.D;   // frame j at + j * PB * CW
   const half_t* vp = Vs + (size_t)pl * CW + hl * p.D;
   const int fstride = p.PB * CW;
-  const int nch = p.D >> 3;
+  const int nch = NCH > 0 ? NCH : (p.D >> 3);
 
   // No per-frame branches: frames beyond F are clamped to F-1 for the loads and masked arithmetically afterwards, so the
   // compiler can batch all FMAX ds_read_b128 of a chunk ahead of the dot products (a branch per frame serialised one
@@ -80,8 +90,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   float s[FMAX];
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) s[j] = 0.f;
-  for (int c = 0; c < nch; ++c) {
-    const half8_t q8 = *reinterpret_cast<const half8_t*>(qp + c * 8);
+  auto score_chunk = [&](int c, const half8_t q8) {
     half8_t k8[FMAX];
 #pragma unroll
     for (int j = 0; j < FMAX; ++j) k8[j] = *reinterpret_cast<const half8_t*>(kp + joff[j] + c * 8);
@@ -92,6 +101,18 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
       for (int e = 0; e < 8; e += 2) a = __builtin_amdgcn_fdot2(half2_t{q8[e], q8[e + 1]}, half2_t{k8[j][e], k8[j][e + 1]}, a, false);
       s[j] = a;
     }
+  };
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      score_chunk(c, qreg[c]);
+      // one chunk's FMAX K rows in registers at a time: left alone, the NCH * FMAX LDS reads are all issued up front and the dot
+      // products sunk behind them (350+ VGPRs); the empty asm pins every partial score before the next chunk's reads
+#pragma unroll
+      for (int j = 0; j < FMAX; ++j) asm volatile("" : "+v"(s[j]) : : "memory");
+    }
+  } else {
+    for (int c = 0; c < nch; ++c) score_chunk(c, *reinterpret_cast<const half8_t*>(qp + c * 8));
   }
   float m = -1.0e30f;
 #pragma unroll
@@ -106,6 +127,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
     l += s[j];
   }
   const float inv = 1.f / l;
+#pragma nounroll
   for (int c = 0; c < nch; ++c) {
     half8_t v8[FMAX];
 #pragma unroll
@@ -125,10 +147,169 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- matrix-core flavour, F <= 16
+// The lane-per-query kernel above is VALU bound (PMC on MI355X, d = 40: VALU 90 % busy at 3.9 TB/s: ~580 VALU instructions
+// per (pixel, head)).  Here ONE WAVE owns a (pixel, head) unit and the two small products run on the matrix core:
+//   S^T[key][query] = K Q^T   v_mfma_f32_16x16x32_f16, A = K fragment (LDS, ds_read_b128), B = Q fragment (global -> registers,
+//                             fetched before the K/V staging is issued), ceil(D / 32) steps, k-slots past D zero filled
+//   softmax over keys         a lane holds keys 4g .. 4g+3 of query m (g = lane / 16, m = lane % 16): 3 in-lane steps + 2 lane
+//                             exchanges (xor 16, xor 32) for the maximum and for the sum
+//   O^T[d][query] = V^T P^T   v_mfma_f32_16x16x16_f16: the S^T accumulator layout IS the B operand layout (keys 4g .. 4g+3 of
+//                             query m), A = V^T tile gathered from the frame-major LDS image with 2-byte reads, ceil(D / 16) tiles
+// Frames >= F are clamped for the loads, masked as keys (-inf) and not stored as queries.  The LDS image keeps the DMA's lane
+// linear order but every frame row carries one extra 16-byte slot, so the 16 frame rows a fragment read touches start 16 bytes
+// apart modulo the 256-byte bank period (unpadded rows of PB * HG * D * 2 = 1280 bytes would all start in the same bank).
+template <int D>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams p) {
+  constexpr int NKS = (D + 31) / 32, NT = (D + 15) / 16, MAXU = 4;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int CW = p.HG * D, cw8 = CW >> 3;
+  const int ngrp = p.H / p.HG;
+  const int grp = blockIdx.x % ngrp;
+  const int pg = (blockIdx.x / ngrp) * p.PB;          // first global (b, pixel) of this workgroup (NB * HW < 2^31: launcher)
+  const int npix = p.NB * p.HW;
+  const int col0 = grp * CW;
+  const int m = lane & 15, g = lane >> 4;
+  const int fm = min(m, p.F - 1);
+  const int nunit = p.PB * p.HG;                       // <= 4 * MAXU (launcher); wave w owns units w, w + 4, ...
+
+  // ---- Q fragments of this wave's units: global -> registers, in flight while K / V are staged
+  half8_t qf[MAXU][NKS];
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int unit = min(wave + 4 * u, nunit - 1);
+    const int pl = unit / p.HG, hl = unit - pl * p.HG;
+    const int gp = min(pg + pl, npix - 1);
+    const int b = gp / p.HW, pix = gp - b * p.HW;
+    const size_t row = ((size_t)b * p.F + fm) * p.HW + pix;
+    const half_t* qp = p.Q + row * p.ldq + col0 + hl * D + 8 * g;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (32 * s + 8 * g < D) v = *reinterpret_cast<const half8_t*>(qp + 32 * s);
+      qf[u][s] = v;
+    }
+  }
+
+  // ---- stage K and V: chunk c -> (frame j, slot); slot < PB * cw8: (pixel, 16-byte column chunk), the last slot is padding
+  const int spr = p.PB * cw8 + 1;                      // 16-byte slots per frame row
+  const int RS = spr * 16;                             // frame row stride in bytes
+  const int nchunk = p.F * spr;
+  const int region = ((nchunk * 16 + 1023) >> 10) << 10;
+  for (int c = t; c < (region >> 4); c += 256) {
+    const int cl = min(c, nchunk - 1);
+    const int j = cl / spr;
+    int sl = cl - j * spr;
+    if (sl == spr - 1) sl = 0;                         // padding slot: any valid address
+    const int pl = sl / cw8, cc = sl - pl * cw8;
+    const int gp = min(pg + pl, npix - 1);
+    const int b = gp / p.HW, pix = gp - b * p.HW;
+    const size_t row = ((size_t)b * p.F + j) * p.HW + pix;
+    const int cbase = __builtin_amdgcn_readfirstlane(c) << 4;
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.K + row * p.ldk + col0 + cc * 8), (lptr_t)(smem + cbase), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.V + row * p.ldv + col0 + cc * 8), (lptr_t)(smem + region + cbase), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const char* Ks = smem;
+  const char* Vs = smem + region;
+  const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;   // ds_bpermute addresses of the lanes holding the other keys of query m
+  auto xch = [](int addr, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); };
+
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int unit = wave + 4 * u;
+    if (unit >= nunit) break;                          // wave uniform
+    const int pl = unit / p.HG, hl = unit - pl * p.HG;
+    const int gp = pg + pl;
+    if (gp >= npix) break;
+    const int ubase = (pl * CW + hl * D) * 2;          // byte offset of this unit's columns inside a frame row
+    // ---- S^T = K Q^T
+    floatx4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      half8_t kf = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (32 * s + 8 * g < D) kf = *reinterpret_cast<const half8_t*>(Ks + fm * RS + ubase + (32 * s + 8 * g) * 2);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][s], sacc, 0, 0, 0);
+    }
+    // ---- softmax over the keys 4g + r of query m
+    float sv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sv[r] = (4 * g + r < p.F) ? sacc[r] * p.scale_log2 : -1.0e30f;
+    float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+    mx = fmaxf(mx, xch(x16, mx));
+    mx = fmaxf(mx, xch(x32, mx));
+    float l = 0.f;
+    half4_t pb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __builtin_amdgcn_exp2f(sv[r] - mx);   // masked keys: exp2(-huge) = 0
+      l += e;
+      pb[r] = (half_t)e;
+    }
+    l += xch(x16, l);
+    l += xch(x32, l);
+    const float inv = 1.f / l;
+    // ---- O^T = V^T P^T, 16 rows of d per tile
+    const int ob = gp / p.HW, opix = gp - ob * p.HW;
+    const size_t orow = ((size_t)ob * p.F + fm) * p.HW + opix;
+    half_t* op = p.O + orow * p.ldo + col0 + hl * D;
+    const half_t* vcol = reinterpret_cast<const half_t*>(Vs + ubase);
+    int vrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vrow[i] = min(4 * g + i, p.F - 1) * (RS >> 1);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int dc = 16 * tt + m;
+      half4_t vf = {0, 0, 0, 0};
+      if (dc < D) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vf[i] = vcol[vrow[i] + dc];
+      }
+      floatx4 o = {0.f, 0.f, 0.f, 0.f};
+      o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pb, o, 0, 0, 0);
+      const int db = 16 * tt + 4 * g;                  // o[r] = O[query m][d = db + r]
+      if (m < p.F && db < D) {
+        const half4_t ov = {(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
+        *reinterpret_cast<half4_t*>(op + db) = ov;
+      }
+    }
+  }
+}
+
+template <int D>
+static void launch_temporal_mfma(TemporalParams p, hipStream_t st) {
+  // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds 48 KiB; then as
+  // many pixels as fit in 48 KiB, at most 16 (pixel, head) units (4 per wave)
+  int HG = p.H;
+  auto lds = [&](int hg, int pb) { return (size_t)2 * ((((size_t)p.F * (pb * hg * D * 2 + 16)) + 1023) / 1024 * 1024); };
+  while (HG > 1 && lds(HG, 1) > 48 * 1024) HG >>= 1;
+  int PB = 16 / HG;
+  while (PB > 1 && lds(HG, PB) > 48 * 1024) --PB;
+  p.HG = HG; p.PB = PB;
+  const size_t smem = lds(HG, PB);
+  const int grid = cdiv((long)p.NB * p.HW, PB) * (p.H / HG);
+  md_ensure_dynamic_lds<temporal_attn_mfma_kernel<D>>(96 * 1024);
+  hipLaunchKernelGGL(temporal_attn_mfma_kernel<D>, dim3(grid), dim3(256), smem, st, p);
+}
+
+template <int FMAX, int NCH>
+static void launch_temporal_nch(const TemporalParams& p, int grid, int threads, size_t smem, hipStream_t st) {
+  md_ensure_dynamic_lds<temporal_attn_kernel<FMAX, NCH>>(96 * 1024);
+  hipLaunchKernelGGL((temporal_attn_kernel<FMAX, NCH>), dim3(grid), dim3(threads), smem, st, p);
+}
+
 template <int FMAX>
 static void launch_temporal(const TemporalParams& p, int grid, int threads, size_t smem, hipStream_t st) {
-  md_ensure_dynamic_lds<temporal_attn_kernel<FMAX>>(96 * 1024);
-  hipLaunchKernelGGL(temporal_attn_kernel<FMAX>, dim3(grid), dim3(threads), smem, st, p);
+  static const int pre = md_env_int("MD_TEMPORAL_QPRE", 1);   // 0: query chunks loaded inside the score loop (A/B)
+  if (pre && p.D == 40) launch_temporal_nch<FMAX, 5>(p, grid, threads, smem, st);
+  else if (pre && p.D == 80) launch_temporal_nch<FMAX, 10>(p, grid, threads, smem, st);
+  else if (pre && p.D == 160 && FMAX <= 16) launch_temporal_nch<FMAX, 20>(p, grid, threads, smem, st);
+  else launch_temporal_nch<FMAX, 0>(p, grid, threads, smem, st);
 }
 
 extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int NB, int F, int HW,
@@ -140,6 +321,15 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
   p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.NB = NB; p.F = F; p.HW = HW; p.H = H; p.D = D;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  static const int use_mfma = md_env_int("MD_TEMPORAL_MFMA", 1);   // 0: lane-per-query kernel for every shape (A/B)
+  if (use_mfma && F <= 16 && (D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31)) {
+    if (D == 40) launch_temporal_mfma<40>(p, (hipStream_t)stream);
+    else if (D == 80) launch_temporal_mfma<80>(p, (hipStream_t)stream);
+    else launch_temporal_mfma<160>(p, (hipStream_t)stream);
+    MD_CHECK_LAUNCH("md_temporal_attention_fwd");
+    return MD_OK;
+  }
   // heads per workgroup: as many as keep one pixel's K+V (4*F*HG*D bytes) within 48 KiB and HG*F lanes within 256
   int HG = H;
   while (HG > 1 && ((size_t)4 * F * HG * D > 48 * 1024 || HG * F > 256)) HG >>= 1;

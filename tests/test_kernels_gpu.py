@@ -219,6 +219,28 @@ def test_instnorm_spade(dev):
     close(ops.instnorm_spade(x.to(dev), gb.to(dev)), ref, what="man")
 
 
+def test_norm_statistics_with_large_mean(dev):
+    """|mean| >> sigma (activation statistics of real checkpoints: channel groups riding on an offset of tens of sigma): the
+    one-sweep E[x^2] - mean^2 in fp32 loses the variance there; the kernels accumulate around a pilot value instead.  Reference
+    in fp64 on the same fp16-rounded inputs."""
+    B, HW, C, G = 2, 9216, 320, 32
+    gen = torch.Generator().manual_seed(77)
+    offs = (torch.rand(B, 1, G, 1, generator=gen) * 2 - 1) * 200.0                      # per (image, group) offset up to +-200
+    x = (offs + 0.25 * torch.randn(B, HW, G, C // G, generator=gen)).reshape(B, HW, C).half()
+    g, b = (1 + 0.1 * rnd(C, seed=78).float()).half(), rnd(C, seed=79)
+    ref = F.group_norm(x.double().permute(0, 2, 1), G, g.double(), b.double(), 1e-5).permute(0, 2, 1).float()
+    out = ops.groupnorm(x.to(dev), g.to(dev), b.to(dev), G, 1e-5, False)
+    close(out, ref, what="groupnorm, |mean| = 800 sigma")
+    # instance norm (MAN): per-channel offsets
+    B, HW, C = 2, 2304, 128
+    offs = (torch.rand(B, 1, C, generator=gen) * 2 - 1) * 100.0
+    x = (offs + 0.25 * torch.randn(B, HW, C, generator=gen)).half()
+    gb = rnd(B, HW, 2 * C, seed=80)
+    n = F.instance_norm(x.double().permute(0, 2, 1), eps=1e-5).permute(0, 2, 1).float()
+    ref = n * (1 + gb.float()[..., :C]) + gb.float()[..., C:]
+    close(ops.instnorm_spade(x.to(dev), gb.to(dev)), ref, what="instance norm, |mean| = 400 sigma")
+
+
 # --------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, B, H, D, Lq, Lk, kv_index=None):
     qh = q.float().view(B, Lq, H, D).transpose(1, 2)
@@ -294,9 +316,10 @@ def test_attention_via_gemm_vt(dev):
     close(out, ref, rtol=2e-2, what="attn via gemm")
 
 
-@pytest.mark.parametrize("F_,HW,D", [(4, 16, 8), (16, 9, 40), (6, 5, 32), (24, 4, 80), (32, 3, 160), (30, 7, 40)])
-def test_temporal_attention(dev, F_, HW, D):
-    NB, H = 2, 8
+@pytest.mark.parametrize("F_,HW,D,NB", [(4, 16, 8, 2), (16, 9, 40, 2), (6, 5, 32, 2), (24, 4, 80, 2), (32, 3, 160, 2), (30, 7, 40, 2), (16, 5, 80, 2), (16, 6, 160, 2),
+                                        (8, 7, 160, 2), (5, 11, 40, 2), (13, 3, 80, 2), (16, 7, 40, 1), (3, 5, 160, 3)])
+def test_temporal_attention(dev, F_, HW, D, NB):
+    H = 8
     C = H * D
     q, k, v = rnd(NB * F_ * HW, C, seed=53), rnd(NB * F_ * HW, C, seed=54), rnd(NB * F_ * HW, C, seed=55)
 
