@@ -7,39 +7,32 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
-// Statistics are the one-sweep sums of (x - k) and (x - k)^2 in fp32, k = the group's mean over PIXEL 0 of the image (its cpg
-// channels): a pilot of the group mean, so the sums stay O(n * sigma) and var = E[(x-k)^2] - E[x-k]^2 does not cancel when
-// |mean| >> sigma (the plain E[x^2] - mean^2 loses the variance at |mean| / sigma ~ 100 in fp32).  Both kernels derive k with
-// this one function, so it is bit-identical on the two sides.  kc: >= C floats of scratch LDS, kg: >= G floats.
-__device__ __forceinline__ void gn_pilot(const half_t* __restrict__ ximg, int C, int G, float* kc, float* kg) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) kc[c] = (float)ximg[c];
-  __syncthreads();
-  const int cpg = C / G;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float a = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += kc[c];
-    kg[g] = a / (float)cpg;
-  }
-  __syncthreads();
-}
-
+// Statistics are the one-sweep sums of (x - k) and (x - k)^2 in fp32, k = the value of the group's FIRST channel at PIXEL 0 of
+// the image: a pilot of the group mean (a sample of the very distribution being normalised), so the sums stay O(n * sigma) and
+// var = E[(x-k)^2] - E[x-k]^2 does not cancel when |mean| >> sigma (the plain E[x^2] - mean^2 loses the variance at
+// |mean| / sigma ~ 100 in fp32).  Both kernels read k from the same element, so it is bit-identical on the two sides; it costs
+// two 2-byte loads per thread (8 when a thread's 8 channels can span more than two groups), no synchronisation.
 // Thread (cc, r): channel chunk cc (8 channels), row lane r.  A block owns `slab` consecutive pixels of one image.
 __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int R, int slab, int nslab) {
-  extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq (first: pilot scratch)
-  __shared__ float kg[64];
+  extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
   const int b = blockIdx.y, sl = blockIdx.x;
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
   const int cpg = C / G;
-  gn_pilot(x + (size_t)b * HW * C, C, G, sh, kg);
+  const half_t* ximg = x + (size_t)b * HW * C;
   float s[8], q[8], k[8];
+  if (cpg >= 8) {                // the 8 channels of a thread lie in at most two groups
+    const int g0 = (cc * 8) / cpg, g1 = (cc * 8 + 7) / cpg;
+    const float k0 = (float)ximg[g0 * cpg], k1 = (float)ximg[g1 * cpg];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    s[e] = q[e] = 0.f;
-    k[e] = kg[(cc * 8 + e) / cpg];
+    for (int e = 0; e < 8; ++e) k[e] = (cc * 8 + e) / cpg == g0 ? k0 : k1;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k[e] = (float)ximg[((cc * 8 + e) / cpg) * cpg];
   }
-  __syncthreads();               // the pilot scratch in sh[] is re-used for the sums below
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   const half_t* base = x + (size_t)b * HW * C + cc * 8;
 #pragma unroll 4
   for (int p = p0 + r; p < p1; p += R) {
@@ -73,14 +66,14 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
 }
 
 __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ part, const half_t* __restrict__ gamma,
-                                const half_t* __restrict__ beta, int HW, int C, int G, int R, int slab, int nslab, float eps, int silu) {
-  __shared__ float mean_s[64], rstd_s[64], kg[64];
-  extern __shared__ float kc[];  // [C] pilot scratch
+                                const half_t* __restrict__ beta, int HW, int C, int G, int R, int slab, int nslab, float eps, int silu, int zigzag) {
+  __shared__ float mean_s[64], rstd_s[64];
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
-  const int b = blockIdx.y, sl = blockIdx.x;
+  // zigzag: walk the slabs in the reverse of the statistics sweep's order, so that the most recently read (still cached) ones
+  // are re-read first
+  const int b = zigzag ? gridDim.y - 1 - blockIdx.y : blockIdx.y, sl = zigzag ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const int cpg = C / G;
-  gn_pilot(x + (size_t)b * HW * C, C, G, kc, kg);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     float a = 0.f, c2 = 0.f;
     const float* pp = part + ((size_t)b * nslab * G + g) * 2;
@@ -91,7 +84,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     const float n = (float)HW * (float)cpg;
     const float mu = a / n;                               // mean of x - k
     const float var = fmaxf(c2 / n - mu * mu, 0.f);
-    mean_s[g] = kg[g] + mu;
+    mean_s[g] = (float)x[(size_t)b * HW * C + g * cpg] + mu;   // + the pilot
     rstd_s[g] = rsqrtf(var + eps);
   }
   __syncthreads();
@@ -138,11 +131,15 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
   if (R < 1) R = 1;
   const int slab = R * 16;
   const int nslab = cdiv(HW, slab);
-  dim3 grid(nslab, B), block(cch * R);
+  // The apply sweep re-reads what the statistics sweep has just read, in reverse order (most recently read slabs first): +3 % at
+  // C = 640, +-0 elsewhere.  Splitting the batch into chunks so that the re-read would be served from the 256-MB memory-side cache
+  // was measured and is a loss at every chunk size (24 MB: 2.7x slower, 96 MB: -12 %): launch gaps and tails, no visible hit-rate gain.
+  static const int zigzag = md_env_int("MD_GN_ZIGZAG", 1);
+  const dim3 grid(nslab, B), block(cch * R);
   const size_t sh = (size_t)2 * R * C * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, HW, C, G, R, slab, nslab);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, (size_t)C * sizeof(float), (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const half_t*)gamma,
-                     (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const half_t*)gamma,
+                     (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu, zigzag);
   MD_CHECK_LAUNCH("md_groupnorm");
   return MD_OK;
 }

@@ -285,11 +285,12 @@ template <int D>
 static void launch_temporal_mfma(TemporalParams p, hipStream_t st) {
   // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds 48 KiB; then as
   // many pixels as fit in 48 KiB, at most 16 (pixel, head) units (4 per wave)
+  static const size_t cap = (size_t)md_env_int("MD_TEMPORAL_LDS_KB", 48) * 1024;
   int HG = p.H;
   auto lds = [&](int hg, int pb) { return (size_t)2 * ((((size_t)p.F * (pb * hg * D * 2 + 16)) + 1023) / 1024 * 1024); };
-  while (HG > 1 && lds(HG, 1) > 48 * 1024) HG >>= 1;
+  while (HG > 1 && lds(HG, 1) > cap) HG >>= 1;
   int PB = 16 / HG;
-  while (PB > 1 && lds(HG, PB) > 48 * 1024) --PB;
+  while (PB > 1 && lds(HG, PB) > cap) --PB;
   p.HG = HG; p.PB = PB;
   const size_t smem = lds(HG, PB);
   const int grid = cdiv((long)p.NB * p.HW, PB) * (p.H / HG);
