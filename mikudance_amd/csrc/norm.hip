@@ -5,6 +5,12 @@
 //                           y + positional encoding of the row's frame (motion_module.py:416-417)
 //   md_instnorm_spade_f16 : InstanceNorm2d(x) * (1 + gamma) + beta   -- src/models/man_module.py:25-31
 #include "common.h"
+#ifndef GN_UNROLL
+#define GN_UNROLL 4
+#endif
+#ifndef GN_SLAB
+#define GN_SLAB 32      // rows per row-lane and slab (same-box sweep on MI355X: 8: -35 %, 16: baseline, 24-32: +9 ... +20 %, 64: -8 %)
+#endif
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
 // Statistics are the one-sweep sums of (x - k) and (x - k)^2 in fp32, k = the value of the group's FIRST channel at PIXEL 0 of
@@ -34,7 +40,7 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   const half_t* base = x + (size_t)b * HW * C + cc * 8;
-#pragma unroll 4
+#pragma unroll GN_UNROLL
   for (int p = p0 + r; p < p1; p += R) {
     const half8_t v = *reinterpret_cast<const half8_t*>(base + (size_t)p * C);
 #pragma unroll
@@ -98,7 +104,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
   }
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
   const size_t base = (size_t)b * HW * C + cc * 8;
-#pragma unroll 4
+#pragma unroll GN_UNROLL
   for (int p = p0 + r; p < p1; p += R) {
     const half8_t v = *reinterpret_cast<const half8_t*>(x + base + (size_t)p * C);
     half8_t o;
@@ -112,12 +118,21 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
   }
 }
 
-extern "C" size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
+// Launch geometry: R row lanes per 8-channel chunk (~512 threads), slabs of GN_SLAB rows per lane -- halved while the grid would
+// not give every CU two workgroups (small images).
+static void gn_geometry(int B, int HW, int C, int& R, int& slab, int& nslab) {
   const int cch = C / 8;
-  int R = 512 / cch;
+  R = 512 / cch;
   if (R < 1) R = 1;
-  const int slab = R * 16;
-  const int nslab = cdiv(HW, slab);
+  int rows = GN_SLAB;
+  while (rows > 8 && (long)B * cdiv(HW, R * rows) < 512) rows >>= 1;
+  slab = R * rows;
+  nslab = cdiv(HW, slab);
+}
+
+extern "C" size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
+  int R, slab, nslab;
+  gn_geometry(B, HW, C, R, slab, nslab);
   return (size_t)B * nslab * G * 2 * sizeof(float);
 }
 
@@ -127,10 +142,8 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
   MD_CHECK_ARG(C / 8 <= 1024, "md_groupnorm: C=%d too large", C);
   MD_CHECK_ARG(ws_bytes >= md_groupnorm_workspace_bytes(B, HW, C, G), "md_groupnorm: workspace too small");
   const int cch = C / 8;
-  int R = 512 / cch;
-  if (R < 1) R = 1;
-  const int slab = R * 16;
-  const int nslab = cdiv(HW, slab);
+  int R, slab, nslab;
+  gn_geometry(B, HW, C, R, slab, nslab);
   // The apply sweep re-reads what the statistics sweep has just read, in reverse order (most recently read slabs first): +3 % at
   // C = 640, +-0 elsewhere.  Splitting the batch into chunks so that the re-read would be served from the 256-MB memory-side cache
   // was measured and is a loss at every chunk size (24 MB: 2.7x slower, 96 MB: -12 %): launch gaps and tails, no visible hit-rate gain.
