@@ -8,6 +8,9 @@
 #ifndef GN_UNROLL
 #define GN_UNROLL 4
 #endif
+#ifndef GN_THREADS
+#define GN_THREADS 512
+#endif
 #ifndef GN_SLAB
 #define GN_SLAB 32      // rows per row-lane and slab (same-box sweep on MI355X: 8: -35 %, 16: baseline, 24-32: +9 ... +20 %, 64: -8 %)
 #endif
@@ -122,7 +125,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
 // not give every CU two workgroups (small images).
 static void gn_geometry(int B, int HW, int C, int& R, int& slab, int& nslab) {
   const int cch = C / 8;
-  R = 512 / cch;
+  R = GN_THREADS / cch;
   if (R < 1) R = 1;
   int rows = GN_SLAB;
   while (rows > 8 && (long)B * cdiv(HW, R * rows) < 512) rows >>= 1;
