@@ -410,6 +410,8 @@ static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
   constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 6 : (D <= 80 ? 3 : 1));
 #elif defined(A2_WPS5)
   constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 5 : (D <= 80 ? 3 : 1));
+#elif defined(A2_QT2_WPS2)
+  constexpr int WPS = QT != 1 ? 2 : (D <= 40 ? 4 : (D <= 80 ? 3 : 1));
 #else
   constexpr int WPS = QT != 1 ? 1 : (D <= 40 ? 4 : (D <= 80 ? 3 : 1));
 #endif

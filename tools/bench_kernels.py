@@ -25,6 +25,8 @@ def timeit(fn, iters=int(os.environ.get("MD_ITERS", "10")), warm=int(os.environ.
 
 
 def rnd(*shape, scale=1.0):
+    if os.environ.get("MD_BENCH_ZERO"):        # power / clock experiment: all-zero operands toggle (almost) no datapath bits
+        return torch.zeros(*shape, device=dev, dtype=torch.float16)
     return (torch.randn(*shape, device=dev) * scale).half()
 
 
