@@ -280,6 +280,30 @@ def test_attention_at_benchmark_sequence_lengths(dev, D, L, qscale):
     assert rel < 2e-2, rel
 
 
+def test_attention_long_forces_rescale(dev):
+    """Same at a length the long-sequence flavours take (Lq >= 1024, Lk % 64 == 0): late keys dominating a few query rows, in
+    different key tiles, so the lazy rescale fires after many tiles of accumulated O^T."""
+    B, H, D, L = 1, 8, 40, 2048
+    q, k, v = rnd(L, H * D, seed=46), rnd(L, H * D, seed=47), rnd(L, H * D, seed=48)
+    k[1500] = q[5] * 4
+    k[2047] = q[1030] * 5
+    k[64] = q[2000] * 3
+    ref = _attn_ref(q, k, v, B, H, D, L, L)
+    out = ops.attention(q.to(dev), k.to(dev), v.t().contiguous().to(dev), B, H, D, L, L)
+    close(out, ref, what="attn long rescale")
+
+
+def test_attention_pingpong_flavour(dev):
+    """The opt-in ping-pong flavour (attention_v3.h, MD_ATTN_PP=1; the knob is read once per process, hence the subprocess) must
+    stay parity-green on the shapes it takes: the benchmark's d = 40 self-attention and the long rescale case."""
+    import os, subprocess, sys
+    env = dict(os.environ, MD_ATTN_PP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "benchmark_sequence_lengths or long_forces_rescale"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "5 passed" in r.stdout, r.stdout[-500:]
+
+
 def test_attention_forces_rescale(dev):
     """Online softmax: a late key dominating one query row forces the max-rescale branch (CDNA guide rule 26)."""
     B, H, D, L = 1, 8, 40, 320
