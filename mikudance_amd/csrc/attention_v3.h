@@ -26,8 +26,9 @@
 // wave and the vector phase of its SIMD partner do NOT overlap, they add up (pairing verified: the two wrong pairings cost
 // another 15 %; s_setprio on either phase, AGPR accumulators and all-zero operands change nothing of that picture).  On this
 // chip a wave's softmax VALU work is hidden only by interleaving it with that SAME wave's MFMAs (attn2's P.V block), not by a
-// partner wave.  Kept as an opt-in flavour (MD_ATTN_PP=1) for the record and as the scaffold for a hand-interleaved
-// two-q-tile kernel; NOT on the default path.
+// partner wave -- and attn2's counters (MFMA 57 % + VALU 69 % busy) say that even there the two pipes are together only ~ 20-25 %
+// of the time: the floor is close to the SUM of MFMA and VALU time.  Kept as an opt-in flavour (MD_ATTN_PP=1) for the record;
+// NOT on the default path.
 #pragma once
 #include <type_traits>
 
