@@ -19,6 +19,9 @@
 //    reads a constant 1.0 from LDS, so S' = log2e*scale*q.k - m comes straight out of the MFMA and the per-score work is
 //    exp2 + pack only (measured on MI355X: this kernel is bound by VALU issue -- 72 % busy vs 47 % for the MFMA pipe --
 //    and the fma was 32 of its ~125 VALU instructions per 64-key tile).  m moves only in the (rare) rescale branch.
+//    Round 2: the reference sits 4 octaves above the running maximum and the "has the maximum grown by > 2^5" test is one OR
+//    over the packed P registers (bit 14 of an fp16 = "P >= 2") instead of a 32-input maximum per tile (+3.5 % same-box; the
+//    maximum is computed on the rare path only; build with -DA2_NO_ORCHECK for the previous form).
 #pragma once
 #include "common.h"
 #include <stdlib.h>
@@ -292,6 +295,56 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
     half8_t pf[QT][4];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
+#ifndef A2_NO_ORCHECK
+      if constexpr (FOLD) {
+        // Reference r (slot D of Q) is kept A2_OFF = 4 octaves ABOVE the row's running maximum, so that P <= 2^-4 as long as the
+        // maximum has not grown and "some P >= 2" -- bit 14 of an fp16, i.e. one OR over the packed P registers instead of a
+        // 32-input maximum -- means "the maximum has grown by more than 2^5" (the lazy-rescale threshold; also catches inf / nan).
+        // The maximum itself is only computed on the rare path, which then re-derives P from the scores it still holds.
+        auto make_p = [&]() {
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              pf[u][sub * 2 + (r >> 3)][r & 7] = (half_t)__builtin_amdgcn_exp2f(s[u][sub][r]);
+              pf[u][sub * 2 + (r >> 3)][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(s[u][sub][r + 1]);
+            }
+        };
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        const bool first = it == 0;
+        bool trig = first;
+        if (!first) {
+          make_p();
+          const uint4v ob = __builtin_bit_cast(uint4v, pf[u][0]) | __builtin_bit_cast(uint4v, pf[u][1]) |
+                            __builtin_bit_cast(uint4v, pf[u][2]) | __builtin_bit_cast(uint4v, pf[u][3]);
+          trig = __any(((ob[0] | ob[1] | ob[2] | ob[3]) & 0x40004000u) != 0);
+        }
+        if (trig) {
+          float mloc = fmaxf(s[u][0][0], s[u][1][0]);
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[u][0][r]), s[u][1][r]);
+          mloc = a2_xhalf_max(mloc) + 4.0f;                           // where the reference should sit, relative to the current one
+          const float want = m_run[u] + (first ? mloc : fmaxf(mloc, 0.f));
+          const float m_new = (float)(half_t)fminf(fmaxf(want, -60000.f), 60000.f);
+          const float d = m_new - m_run[u];
+          m_run[u] = m_new;
+          if (hi) qf[u][KS - 1][0] = (half_t)(-m_new);
+          if (!first) {
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[u][t][r] *= alpha;
+          }
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][sub][r] -= d;
+          make_p();
+        }
+        continue;
+      }
+#endif
       float mloc = fmaxf(s[u][0][0], s[u][1][0]);
 #pragma unroll
       for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[u][0][r]), s[u][1][r]);
