@@ -1,0 +1,71 @@
+"""The bench.py output contract, checked on the committed record of the last GPU run (profiles/r02_bench.json) and on the
+command line defaults -- no GPU needed.  Catches a renamed key, a wrong unit or an inconsistent roofline / value before the
+driver does."""
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        lines = [l for l in f.read().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py prints ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_keys():
+    d = _record("r02_bench.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                 ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
+    assert d["unit"] == base.get("unit", "frames/s") or d["unit"] == "frames/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f16" and d["data"] == "synthetic"
+    assert d["n_gpus"] == 1 and "workload" in d["config"] and "configs[1]" in d["config"]["workload"]
+    assert not any(k in d["config"] for k in ("model", "seq_len", "global_batch"))
+    # value = frames of the clips / wall time: 16 frames per step
+    frames = int(re.search(r"(\d+)f,", d["metric"]).group(1))
+    assert math.isclose(d["value"], frames / (d["ms_per_step"] * 1e-3), rel_tol=1e-6)
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _record("r02_bench.json")
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert (r["bound"] == "mfma") == (r["unit"] == "TFLOP/s")
+    assert math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-9) and 0.0 < r["frac"] < 1.0
+    assert r["peak"] == (2500.0 if r["bound"] == "mfma" else 8000.0)
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes"] > 0
+    if r["traffic"] is not None:
+        assert os.path.exists(os.path.join(ROOT, r["traffic_source"]["file"]))
+    # the dominant kernel's time is a part of a step, not more
+    assert r["avg_ms"] * r["launches"] / d.get("steps", 1) <= d["ms_per_step"] * 1.5
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert c["value"] < d["value"]
+    # executed work never exceeds the machine: whole-loop MFMA fraction below 1
+    assert 0.0 < d["mfma_frac_whole_loop"] < 1.0
+
+
+def test_other_records_are_labelled_with_their_config():
+    assert "configs[2]" in _record("r02_bench_cfg2.json")["config"]["workload"]
+    c4 = _record("r02_bench_cfg4.json")
+    assert "configs[4]" in c4["config"]["workload"] and "1024x1024" in c4["metric"] and c4["peak_hbm_gb"] < 288
+    two = _record("r02_bench_2rank_gloo_small.json")
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "dp2"
+
+
+def test_command_line_defaults():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300).stdout
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert re.search(r'"--gpus", type=int, default=1\b', src) and re.search(r'"--size", type=int, default=768\b', src)
+    assert re.search(r'"--frames", type=int, default=16\b', src) and re.search(r'"--ddim-steps", type=int, default=20\b', src)
