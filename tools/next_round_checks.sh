@@ -1,0 +1,13 @@
+#!/bin/bash
+# First GPU call of the next round: validate and A/B what was written after round 2's GPU budget ran out (all default-off).
+#   MD_GEMM_PP_DIRECT=1  plain ping-pong epilogue straight from the accumulators (gemm_pp.h)
+R=${GRAFT_REPO_ROOT:-.}
+O=$R/gpurun_out/next
+mkdir -p $O
+cd $R
+MD_GEMM_PP=1 MD_GEMM_PP_DIRECT=1 python tests/gemm_pp_check.py > $O/pp_direct_check.log 2>&1; echo "pp direct parity rc=$?"; tail -3 $O/pp_direct_check.log
+for r in 1 2; do for d in 0 1; do echo "== MD_GEMM_PP_DIRECT=$d (round $r)"; MD_GEMM_PP_DIRECT=$d python tools/bench_kernels.py gemm conv 2>&1 | grep -v amdgpu; done; done > $O/ab_pp_direct.log 2>&1; cat $O/ab_pp_direct.log
+for d in 0 1; do MD_GEMM_PP_DIRECT=$d python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); f=d['kernel_families']
+print('MD_GEMM_PP_DIRECT=$d: %.3f f/s  gemm %.0f ms  conv %.0f' % (d['value'], f['gemm']['ms_per_clip'], f['conv3x3']['ms_per_clip']))"; done
