@@ -7,6 +7,8 @@ mkdir -p $O
 cd $R
 MD_GEMM_PP=1 MD_GEMM_PP_DIRECT=1 python tests/gemm_pp_check.py > $O/pp_direct_check.log 2>&1; echo "pp direct parity rc=$?"; tail -3 $O/pp_direct_check.log
 for r in 1 2; do for d in 0 1; do echo "== MD_GEMM_PP_DIRECT=$d (round $r)"; MD_GEMM_PP_DIRECT=$d python tools/bench_kernels.py gemm conv 2>&1 | grep -v amdgpu; done; done > $O/ab_pp_direct.log 2>&1; cat $O/ab_pp_direct.log
+# the full per-shape table (the bench JSON keeps only the top 16): where the transposed-output (V^T) projections and the 12x12 level sit
+MD_BENCH_DUMP=$O/shapes_all.txt python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; head -60 $O/shapes_all.txt
 for d in 0 1; do MD_GEMM_PP_DIRECT=$d python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); f=d['kernel_families']
