@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 
 #include "attention_v2.h"
 #include "attention_v3.h"
+#include "attention_v2s.h"
 #include <stdlib.h>
 
 template <int D>
@@ -226,6 +227,12 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
     // long self / mixed attention of the 96x96 level: ping-pong flavour (attention_v3.h), MD_ATTN_PP = 0 | 1
     static const int pp = md_env_int("MD_ATTN_PP", 0);
     if (fast && pp && p.Lk % A2_KT == 0 && p.Lk >= 2 * A2_KT && p.Lq >= 1024) return launch_attn3<D>(p, stream);
+  }
+  if constexpr (D == 40 || D == 80) {
+    // cross-attention (a handful of key tiles): K / V^T resident in LDS, persistent walk over the q-blocks (attention_v2s.h);
+    // opt-in until validated on hardware
+    static const int small = md_env_int("MD_ATTN_SMALL", 0);
+    if (fast && small && attn2s_eligible<D>(p)) return launch_attn2s<D>(p, stream);
   }
   if (fast) return launch_attn2<D>(p, stream);
   constexpr int KS = (D + 15) / 16, DQ = KS * 16, DVT = (D + 31) / 32;

@@ -77,6 +77,13 @@ def main(which):
             o = torch.empty((B * L, C), device=dev, dtype=torch.float16)
             ms = timeit(lambda: ops.attention(q, k, vt, B, 8, D, L, L, out=o))
             out[f"attn B={B} L={L} D={D}"] = (ms, 4.0 * B * 8 * L * L * D / ms / 1e9)
+    if "xattn" in which:       # cross-attention of the UNets: 257 CLIP tokens padded to 264 per frame
+        for B, L, D in [(32, 9216, 40), (32, 2304, 80), (32, 576, 160)]:
+            C, Lk, ks = 8 * D, 257, 264
+            q, k, vt = rnd(B * L, C), rnd(B * ks, C), rnd(C, B * ks)
+            o = torch.empty((B * L, C), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.attention(q, k, vt, B, 8, D, L, Lk, kv_stride=ks, out=o))
+            out[f"xattn B={B} Lq={L} Lk={Lk} D={D}"] = (ms, 4.0 * B * 8 * L * Lk * D / ms / 1e9)
     if "temporal" in which:
         for HW, D in [(9216, 40), (2304, 80), (576, 160), (144, 160)]:
             C, F_ = 8 * D, 16
