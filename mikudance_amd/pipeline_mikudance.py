@@ -15,7 +15,6 @@ Result-preserving reductions (proven identical on the
   * unconditional rows ignore the bank -> one attention pass with a per-row K/V source replaces two.
 `reference_reuse=False` restores the literal per-step evaluation (same results, for A/B timing).
 """
-import math
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .blocks import MANModule, tokens
+from .blocks import MANModule
 from .unet_3d_mix import _Config, _UNetBase
 
 

@@ -6,7 +6,6 @@ API mirror of the reference `UNet3DConditionModel` (src/models/unet_3d_mix.py:34
 Internally frames are folded into the batch and everything runs NHWC fp16 on the HIP kernels.
 """
 import json
-import os
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional
