@@ -60,6 +60,9 @@ def main():
     from mikudance_amd.synth import synth_inputs
 
     rank, world = dp.init()
+    if world > 1:
+        # N ranks share the host: cap the intra-op pool (weight synthesis, packing) so that 8 ranks do not spin 8 x 128 threads
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())

@@ -224,8 +224,8 @@ class CLIPVisionModelWithProjection(nn.Module):
         c.update({k: v for k, v in kw.items() if k in c})
         if c["hidden_act"] != "quick_gelu" or c["num_channels"] != 3:
             raise NotImplementedError("CLIPVisionModelWithProjection (MI355X): only quick_gelu / RGB towers are implemented")
-        if (c["hidden_size"] // c["num_attention_heads"]) % 8 or (c["hidden_size"] // c["num_attention_heads"]) > 160:
-            raise NotImplementedError("attention head dim must be a multiple of 8, <= 160")
+        if c["hidden_size"] // c["num_attention_heads"] not in (8, 16, 32, 40, 64, 80, 160):
+            raise NotImplementedError("attention head dim must be one of 8 / 16 / 32 / 40 / 64 / 80 / 160 (md_attention_fwd_f16)")
         self.config = SimpleNamespace(**c)
         self.vision_model = CLIPVisionTransformer(self.config)
         self.visual_projection = _Projection(c["hidden_size"], c["projection_dim"])

@@ -107,7 +107,9 @@ __global__ void cfg_ddim_kernel(half_t* __restrict__ lat, const float* __restric
   const long total = (long)Ftot * HW4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int fr = (int)(idx / HW4);
-    const float inv = 1.f / counter[fr];
+    // without guidance the reference takes the window SUM as it is: its division by the counter sits inside
+    // `if do_classifier_free_guidance:` (src/pipelines/pipeline_mikudance.py:670-674)
+    const float inv = halves == 2 ? 1.f / counter[fr] : 1.f;
     float v = noise_sum[idx] * inv;
     if (halves == 2) {
       const float c = noise_sum[total + idx] * inv;

@@ -466,8 +466,25 @@ static void launch_variant(GemmParams& p, hipStream_t stream) {
 
 static int env_int(const char* name, int dflt) { return md_env_int(name, dflt); }
 
+
+static int md_device_cus() {
+  // CU count of the CURRENT device, cached per device (a process may drive several GPUs)
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cache[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (n <= 0 || (n & 7)) n = 256;                               // MI355X: 256 CUs; the tile order needs a multiple of 8
+    cache[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 #include "gemm_pp.h"
 #include "gemm_ws.h"
+#include "gemm_sp.h"
 
 template <int KS, int CB, int TPR, bool RES, bool RA>
 static void launch_ws_variant(const WsParams& p, hipStream_t stream) {
@@ -539,6 +556,11 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   static const int big = env_int("MD_GEMM_BIG", -1);       // -1: automatic
   static const int narrow = env_int("MD_GEMM_NARROW", 0);
   static const int pp = env_int("MD_GEMM_PP", 2);          // 0: off, 1: every eligible problem, 2: automatic
+  static const int sp = env_int("MD_GEMM_SP", 0);          // one-wave-per-SIMD flavour (gemm_sp.h): 0 off, 1 every eligible problem, 2 automatic
+  if (sp == 1 && sp_eligible<CONV, GEGLU>(p)) {
+    launch_sp<CONV, GEGLU>(p, stream);
+    return;
+  }
   // ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
   // loop long enough to amortise its prologue / epilogue, which no other workgroup covers.  Same-box A/B on MI355X:
   // +25..28 % on the 96x96 convs (950-1000 TF), +16 % on M=294912 N=320 K=1280, +3..6 % on the K >= 640 GEGLU GEMMs and the
@@ -628,7 +650,15 @@ static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
     // in-place residual is part of the contract (header: Aliasing); anything else that overlaps the output is not
     const uintptr_t c0 = reinterpret_cast<uintptr_t>(p.C), r0 = reinterpret_cast<uintptr_t>(p.residual);
     const size_t cbytes = ((size_t)(p.M - 1) * p.ldc + p.N) * 2, rbytes = ((size_t)(p.M - 1) * p.ldr + p.N) * 2;
-    MD_CHECK_ARG(p.transpose_out || r0 + rbytes <= c0 || c0 + cbytes <= r0, "md_gemm: residual partially overlaps the output");
+    bool disjoint = r0 + rbytes <= c0 || c0 + cbytes <= r0;
+    if (!disjoint && p.ldr == p.ldc && ((c0 > r0 ? c0 - r0 : r0 - c0) & 1) == 0) {
+      // column-sliced siblings of ONE wider row-major buffer (residual = buf[:, :N], out = buf[:, N:]): the bounding ranges
+      // interleave, but no element is shared when the two column intervals stay apart within the common row pitch
+      const size_t ld = (size_t)p.ldc;
+      const size_t d = ((c0 > r0 ? c0 - r0 : r0 - c0) / 2) % ld;
+      disjoint = d >= (size_t)p.N && d + (size_t)p.N <= ld;
+    }
+    MD_CHECK_ARG(p.transpose_out || disjoint, "md_gemm: residual partially overlaps the output");
   } else if (p.residual) {
     MD_CHECK_ARG(p.ldr == p.ldc, "md_gemm: in-place residual needs ldr == ldc");
   }
@@ -659,6 +689,9 @@ static int conv3x3_common(const void* X, const void* W, void* Y, int ldy, int B,
   MD_CHECK_ARG(stride == 1 || stride == 2, "md_conv3x3: stride must be 1 or 2");
   MD_CHECK_ARG(upsample == 0 || (upsample == 1 && stride == 1), "md_conv3x3: upsample is 0 or 1 (nearest 2x) with stride 1");
   MD_CHECK_ARG(pad_lo == 1 || (pad_lo == 0 && stride == 2 && upsample == 0), "md_conv3x3: pad_lo is 1, or 0 with stride 2 (pad (0,1,0,1))");
+  // the A gather computes (iy * Win + ix) * Cin with 24-bit multiplies into a 32-bit element offset (per image)
+  MD_CHECK_ARG((long)Hin * Win < (1L << 24) && Cin < (1 << 24) && (long)Hin * Win * Cin < (1L << 32),
+               "md_conv3x3: image %dx%dx%d exceeds the tap arithmetic (Hin*Win < 2^24 pixels, Hin*Win*Cin < 2^32 elements)", Hin, Win, Cin);
   GemmParams p = {};
   p.A = (const half_t*)X; p.W = (const half_t*)W; p.C = (half_t*)Y;
   p.bias = (const half_t*)bias; p.residual = (const half_t*)residual; p.rowadd = (const half_t*)rowadd;

@@ -697,12 +697,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ppg_kernel(GemmParams p) {
 static void launch_ppg(GemmParams& p, hipStream_t stream) {
   constexpr size_t smem = (size_t)4 * (256 + 256) * 64;
   md_ensure_dynamic_lds<gemm_ppg_kernel>((int)smem);
-  static const int ncu = [] {                                    // MI355X: 256 CUs (one persistent workgroup each)
-    int dev = 0, n = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    return (n <= 0 || (n & 7)) ? 256 : n;
-  }();
+  const int ncu = md_device_cus();                                // MI355X: 256 CUs (one persistent workgroup each), per device
   p.tiles_n = p.N / 256;
   p.tiles_total = cdiv(p.M, 256) * p.tiles_n;
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;

@@ -1,0 +1,385 @@
+// gemm_sp_kernel: the "one wave per SIMD" flavour of the MFMA GEMM / implicit-GEMM 3x3 convolution (included by gemm.hip; same
+// operands, LDS image, swizzle and epilogue arithmetic as gemm_kernel / gemm_pp_kernel).
+//
+// Why a third structure.  gemm_pp_kernel keeps two waves per SIMD and alternates them between a fragment-load slot and an MFMA
+// slot with a workgroup barrier in between; its load slot (14 ds_read_b128 + 4-5 DMA pieces, ~830 cycles) is longer than its
+// MFMA slot (20 MFMAs, ~700 cycles), so the matrix pipe of a SIMD is busy ~64 % of the time at best, and with 256 registers
+// per wave the wave tile is 64 x 160 (0.7 fragment reads per MFMA).  Here a 256-thread workgroup owns the CU with ONE wave per
+// SIMD and the whole 512-register file per lane:
+//   * wave tile (32 MT) x (32 NT), wave grid 2 x 2: MT = 3, NT = 5 -> 192 x 320 tiles (240 accumulator registers, 8 fragment
+//     reads per 15 MFMAs; 192 divides every token count of the UNets and gives 294 912 x 320 six and 73 728 x 640 three exact
+//     rounds of 256 CUs); MT = NT = 4 -> 256 x 256 for GEGLU (h | g column pairing needs 64-column groups per wave);
+//   * the wave is software pipelined against ITSELF: the fragments of k-step u+1 are read into the other register set and
+//     the DMA pieces of the K tile 3-4 ahead are issued in the issue slots BETWEEN the MFMAs of step u (sched_group_barrier
+//     pins one ds_read_b128 behind each of the first MT + NT MFMAs and one DMA piece behind every fourth), so the matrix pipe
+//     never waits for a load slot;
+//   * K tiles of 32 in a 4-deep 32-KiB LDS ring filled by direct-to-LDS DMA (three tiles in flight, counted vmcnt), ONE
+//     s_barrier per K tile (per 30-32 MFMAs of every wave);
+//   * persistent: a workgroup walks over its output tiles and the ring keeps running across tile boundaries; the first k-step
+//     of an output tile accumulates onto the inline constant 0 (no accumulator clearing);
+//   * epilogue straight from the accumulators (operand roles swapped, acc = mfma(W, A): a lane owns ONE output row and four
+//     4-column pieces per 32-column sub-tile): v_permlane32_swap pairs the pieces of the two lane halves into 16-byte stores
+//     (and un-pairs 16-byte residual loads), no LDS staging, no barrier.
+// Synchronisation (tile g in ring slot g & 3; B_g = the barrier in the middle of tile g-1's body):
+//   body(g):  half 1: MFMA(g, k 0-15)  || read (g, k 16-31) -> F1 || DMA pieces 4-7 of tile g+3
+//             lgkmcnt(0), vmcnt(16): this wave's pieces of tile g+1 have landed; B_{g+1}
+//             half 2: MFMA(g, k 16-31) || read (g+1, k 0-15) -> F0 || DMA pieces 0-3 of tile g+4
+//   RAW: all pieces of tile g+1 are retired by their issuing waves before B_{g+1}; its first reader comes after B_{g+1}.
+//   WAR: slot g & 3 is refilled (tile g+4) after B_{g+1}; every read of tile g was retired (lgkmcnt(0)) before B_{g+1}.
+//   vmcnt counts stores too, but loads return in order: "at most 16 outstanding" implies that every load older than the 16
+//   youngest loads has landed whatever the epilogue's stores do (at worst it waits for old stores as well).
+// DMA pieces are issued unconditionally (beyond the last K tile they re-read the last tile's first columns into a ring slot
+// nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
+#pragma once
+
+// zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
+__device__ __attribute__((aligned(64))) half_t g_zero_cols[16384] = {};
+
+// One accumulator element, AGPR -> VGPR, at the point of use.  The "a" constraint keeps the MFMA accumulators in the accumulator
+// half of the register file for the whole kernel (left to itself the register allocator copies all 240-256 of them into
+// VGPRs at the top of the epilogue, which evicts the main loop's fragments and pointers into scratch).
+__device__ __forceinline__ float sp_acc(const floatx16& a, int r) {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a[r]));
+  return x;
+}
+
+// Plain epilogue of one wave's (32 MT) x (32 NT) accumulator block, straight from the registers.  acc = mfma(W, A): lane
+// (lc = lane % 32, hi = lane / 32) holds, for output row mw + 32 i + lc, the columns 8 g + 4 hi + {0..3}, g = 0..3 of every
+// 32-column sub-tile j.  v_permlane32_swap pairs the 8-byte pieces of the two lane halves into 16-byte stores (guide T21) and
+// un-pairs 16-byte residual loads (same instruction: it is an involution).  act == ACT_NONE (launcher).
+template <int MT, int NT, bool RES>
+__device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][NT], int mw, int nw, int lc, int hi) {
+  const half_t* bias = p.bias ? p.bias : g_zero_cols;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mw + i * 32 + lc;
+    const bool row_ok = m < p.M;
+    const int mc = row_ok ? m : p.M - 1;
+    const half_t* ra = p.rowadd ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra : g_zero_cols;
+    const half_t* rrow = RES ? p.residual + (size_t)mc * p.ldr : nullptr;
+    half_t* crow = p.C + (size_t)mc * p.ldc;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nc = nw + j * 32;                                  // first column of this 32-column sub-tile
+      unsigned rp[4][2];
+      if constexpr (RES) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const uint4 r4 = *reinterpret_cast<const uint4*>(rrow + nc + 16 * pr + 8 * hi);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(r4.x, r4.z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(r4.y, r4.w, false, false);
+          rp[2 * pr][0] = s0[0]; rp[2 * pr][1] = s1[0];
+          rp[2 * pr + 1][0] = s0[1]; rp[2 * pr + 1][1] = s1[1];
+        }
+      }
+      unsigned w[4][2];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int c = nc + 8 * gi + 4 * hi;
+        const half4_t bv = *reinterpret_cast<const half4_t*>(bias + c);
+        const half4_t av = *reinterpret_cast<const half4_t*>(ra + c);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sp_acc(acc[i][j], 4 * gi + e) + (float)bv[e] + (float)av[e];
+        if constexpr (RES) {
+          half4_t rv;
+          __builtin_memcpy(&rv, rp[gi], 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        __builtin_memcpy(w[gi], &o, 8);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
+        if (row_ok) {
+          const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<uint4*>(crow + nc + 16 * pr + 8 * hi) = v4;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                           // one sub-tile at a time: keeps the live ranges short
+    }
+  }
+}
+
+template <bool CONV, bool GEGLU, int MT, int NT>
+__global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
+  constexpr int BK = 32;
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;
+  constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows, W rows
+  constexpr int G = PA + PB;
+  static_assert(G == 8, "the issue schedule below places 4 + 4 pieces per K tile");
+  static_assert(!GEGLU || NT % 2 == 0, "GEGLU pairs 32-column sub-tiles (2q, 2q+1) of a wave");
+  constexpr int OPA = BM * ROWB, STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = lane >> 2, pslot = lane & 3;
+  const int nk = p.K / BK;
+  const int nwg = p.tiles_total;
+  const int ntile = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // output tiles of this workgroup
+
+  auto tile_origin = [&](int i, int& m0, int& n0) {
+    // virtual workgroup id -> tile: every XCD (workgroup b runs on XCD b % 8) walks a contiguous run of tiles, n fastest, so the
+    // A row panel / W panel it re-reads stay in its private L2 (gridDim.x % 8 == 0 or gridDim.x == nwg)
+    const int v = (int)blockIdx.x + i * (int)gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    m0 = (t / p.tiles_n) * BM;
+    n0 = (t % p.tiles_n) * BN;
+  };
+
+  // ------------------------------------------------------------------ issue side (runs 3-4 K tiles ahead of the compute side)
+  const half_t* a_src[PA];
+  const half_t* w_src[PB];
+  int a_oy[PA], a_ox[PA];
+  auto set_sources = [&](int i) {
+    int m0, n0;
+    tile_origin(i, m0, n0);
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int row = (wave * PA + j) * RPI + lrow;
+      const int lslot = pslot ^ ((row >> 2) & 3);             // source-side swizzle (the DMA writes LDS lane-linearly)
+      const int m = m0 + row;
+      const int mm = m < p.M ? m : p.M - 1;
+      if (CONV) {
+        const int hw = p.Hout * p.Wout;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        a_oy[j] = oy * p.stride - p.pad;
+        a_ox[j] = ox * p.stride - p.pad;
+        a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
+      } else {
+        a_oy[j] = a_ox[j] = 0;
+        a_src[j] = p.A + (size_t)mm * p.lda + lslot * 8;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int row = (wave * PB + j) * RPI + lrow;
+      w_src[j] = p.W + (size_t)(n0 + row) * p.K + (pslot ^ ((row >> 2) & 3)) * 8;      // N % BN == 0 (launcher)
+    }
+  };
+  const half_t* zero_src = g_zero_page + 0;
+  int is_it = 0, is_kt = 0;                       // output tile / K tile of the next tile to issue
+  int is_k0 = 0, is_c0 = 0, is_ky = 0, is_kx = 0;  // its K offset; conv: filter tap and first channel (k0 = tap * Cin + c0)
+  set_sources(0);
+  // one DMA instruction (piece) of the tile being issued: pieces 0 .. PA-1 are A rows, PA .. G-1 W rows
+  auto issue_piece = [&](int stage, int pc) {
+    if (pc < PA) {
+      char* dst = smem + stage * STAGE + (wave * PA + pc) * 1024;
+      if (CONV) {
+        const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
+        const int iy = a_oy[pc] + is_ky, ix = a_ox[pc] + is_kx;
+        const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
+        unsigned off = __umul24(__umul24((unsigned)(iy >> p.upsample), (unsigned)p.Win) + (unsigned)(ix >> p.upsample), (unsigned)p.Cin) + is_c0;
+        asm volatile("" : "+v"(off));
+        const half_t* src = a_src[pc] + off;
+        src = ok ? src : zero_src;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[pc] + is_k0), (lptr_t)dst, 16, 0, 0);
+      }
+    } else {
+      const int j = pc - PA;
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + is_k0), (lptr_t)(smem + stage * STAGE + OPA + (wave * PB + j) * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_advance = [&]() {
+    is_k0 += BK;
+    if (CONV) {
+      is_c0 += BK;
+      if (is_c0 == p.Cin) {
+        is_c0 = 0;
+        if (++is_kx == 3) { is_kx = 0; ++is_ky; }
+      }
+    }
+    if (++is_kt == nk) {
+      is_kt = 0;
+      is_k0 = is_c0 = is_ky = is_kx = 0;
+      if (++is_it < ntile) set_sources(is_it);      // past the last tile: keep its sources (valid addresses, data never read)
+    }
+  };
+
+  // ------------------------------------------------------------------ compute side
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_rd[2][MT], b_rd[2][NT];                    // per-lane LDS byte offsets of the fragment reads of k-step s = 0, 1
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ra = wm * (32 * MT) + i * 32 + frow;
+      a_rd[s][i] = ra * ROWB + (((s * 2 + fhi) ^ ((ra >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int rb = wn * (32 * NT) + j * 32 + frow;
+      b_rd[s][j] = OPA + rb * ROWB + (((s * 2 + fhi) ^ ((rb >> 2) & 3)) << 4);
+    }
+  }
+  floatx16 acc[MT][NT];
+  half8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+
+#define SP_READ(FA, FB, SB, S)                                                                              \
+  {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *reinterpret_cast<const half8_t*>((SB) + a_rd[S][i]); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) FB[j] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][j]); \
+  }
+  // One k-step (half a K tile), issue order pinned by hand (sched_barrier(0) lets nothing cross): MFMA k of the current
+  // fragments (FAU, FBU), then -- behind each of the first MT + NT MFMAs -- ONE ds_read_b128 of the next k-step's fragments (FAL,
+  // FBL from ring stage SB, k-step S), and behind MFMAs 1, 4, 7, 10 ONE DMA piece (PC0 ..) into ring stage DST.  All four waves
+  // of the workgroup leave the barrier together, so a burst of 8 reads + 4 pieces per wave would queue up in front of the
+  // LDS / texture path and stall the in-order wave's next MFMA; spread out, every gap carries at most three instructions.
+#define SP_HALF(FAU, FBU, FAL, FBL, SB, S, ZERO, DST, PC0)                                                  \
+  {                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < MT * NT; ++k) {                                                   \
+      const int i = k / NT, j = k % NT;                                                                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FBU[j], FAU[i], (ZERO) ? floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[i][j], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      if (k < MT) {                                                                                         \
+        FAL[k < MT ? k : 0] = *reinterpret_cast<const half8_t*>((SB) + a_rd[S][k < MT ? k : 0]);            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      } else if (k < MT + NT) {                                                                             \
+        FBL[k < MT ? 0 : k - MT] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][k < MT ? 0 : k - MT]);  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      }                                                                                                     \
+      if (k % 3 == 1 && k < 12) {                                                                           \
+        issue_piece(DST, (PC0) + k / 3);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+
+  // ------------------------------------------------------------------ prologue: tiles 0, 1, 2 and the first half of tile 3
+#pragma unroll 1
+  for (int s = 0; s < 3; ++s) {
+#pragma unroll
+    for (int pc = 0; pc < G; ++pc) issue_piece(s, pc);
+    issue_advance();
+  }
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) issue_piece(3, pc);
+  wait_vmcnt<2 * G + 4>();                                           // this wave's pieces of tile 0
+  __builtin_amdgcn_s_barrier();
+  SP_READ(fa0, fb0, smem, 0)
+
+  // One K tile of the main loop.  ZERO: first K tile of an output tile (its first k-step accumulates onto the inline constant 0).
+  // The first K tile is PEELED out of the K loop instead of being selected inside it: a select would merge two definitions of
+  // every accumulator at one program point, and the register allocator then shuffles the 240 accumulators through VGPRs and
+  // scratch on every iteration.
+#define SP_BODY(ZERO)                                                                                       \
+  {                                                                                                         \
+    const char* sb = smem + (g & 3) * STAGE;                                                                \
+    const char* sbn = smem + ((g + 1) & 3) * STAGE;                                                         \
+    /* half 1: MFMA (g, k 0-15) || read (g, k 16-31) -> F1 || pieces 4-7 of tile g+3 */                     \
+    SP_HALF(fa0, fb0, fa1, fb1, sb, 1, ZERO, (g + 3) & 3, 4)                                                \
+    issue_advance();                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    wait_vmcnt<2 * G>(); /* this wave's pieces of tile g+1 (tiles g+2, g+3 may fly) */                      \
+    __builtin_amdgcn_s_barrier(); /* B_{g+1} */                                                             \
+    /* half 2: MFMA (g, k 16-31) || read (g+1, k 0-15) -> F0 || pieces 0-3 of tile g+4 -> the slot tile g has left */ \
+    SP_HALF(fa1, fb1, fa0, fb0, sbn, 0, false, g & 3, 0)                                                    \
+    ++g;                                                                                                    \
+  }
+
+  int g = 0;
+#pragma unroll 1
+  for (int ct = 0; ct < ntile; ++ct) {
+    SP_BODY(true)
+#pragma unroll 1
+    for (int kt = 1; kt < nk; ++kt) SP_BODY(false)
+    {
+      // ---- epilogue of output tile ct, straight from the accumulators
+      int m0, n0;
+      tile_origin(ct, m0, n0);
+      const int lc = lane & 31, hi = lane >> 5;
+      // the last MFMAs are still writing their accumulators: 18 wait states before the first v_accvgpr_read (the hazard recognizer
+      // does not look inside asm statements)
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      if constexpr (GEGLU) {
+        // sub-tile 2q is h, 2q+1 is g of the same outputs (weight rows packed as [32 h | 32 g] blocks)
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+          const int nc = n0 + wn * (32 * NT) + q * 64;
+          half4_t bh[4], bg[4];
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            bh[gi] = half4_t{0, 0, 0, 0};
+            bg[gi] = half4_t{0, 0, 0, 0};
+            if (p.bias) {
+              bh[gi] = *reinterpret_cast<const half4_t*>(p.bias + nc + 8 * gi + 4 * hi);
+              bg[gi] = *reinterpret_cast<const half4_t*>(p.bias + nc + 32 + 8 * gi + 4 * hi);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * (32 * MT) + i * 32 + lc;
+            const int mc = m < p.M ? m : p.M - 1;
+            half_t* drow = p.C + (size_t)mc * p.ldc + (nc >> 1);
+            unsigned w[4][2];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+              half4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                o[e] = (half_t)((sp_acc(acc[i][2 * q], 4 * gi + e) + (float)bh[gi][e]) * gelu_fast(sp_acc(acc[i][2 * q + 1], 4 * gi + e) + (float)bg[gi][e]));
+              __builtin_memcpy(w[gi], &o, 8);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
+              if (m < p.M) {
+                const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<uint4*>(drow + 16 * pr + 8 * hi) = v4;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+        // bias and the row-broadcast term are always added (absent: a page of zeros, pitch 0), the residual splits the code once
+        if (p.residual) sp_plain_epilogue<MT, NT, true>(p, acc, m0 + wm * (32 * MT), n0 + wn * (32 * NT), lc, hi);
+        else sp_plain_epilogue<MT, NT, false>(p, acc, m0 + wm * (32 * MT), n0 + wn * (32 * NT), lc, hi);
+      }
+    }
+  }
+  wait_vmcnt<0>();                                                   // the DMA pieces issued past the last tile
+#undef SP_BODY
+#undef SP_READ
+#undef SP_HALF
+}
+
+template <bool CONV, bool GEGLU>
+static bool sp_eligible(const GemmParams& p) {
+  constexpr int BN = GEGLU ? 256 : 320;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.transpose_out || p.N % BN != 0 || p.K % 32 != 0 || p.K < 128 || p.N > 16384) return false;
+  if (!GEGLU && p.act != ACT_NONE) return false;
+  if (CONV && p.Cin % 32 != 0) return false;
+  if (!al16(p.C) || p.ldc % 8 != 0) return false;
+  if (p.bias && !al16(p.bias)) return false;
+  if (p.residual && (!al16(p.residual) || p.ldr % 8 != 0)) return false;
+  if (p.rowadd && (!al16(p.rowadd) || p.ldra % 8 != 0)) return false;
+  return true;
+}
+
+template <bool CONV, bool GEGLU>
+static void launch_sp(GemmParams& p, hipStream_t stream) {
+  constexpr int MT = GEGLU ? 4 : 3, NT = GEGLU ? 4 : 5;
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr size_t smem = (size_t)4 * (BM + BN) * 64;
+  md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
+  p.tiles_n = p.N / BN;
+  p.tiles_total = cdiv(p.M, BM) * p.tiles_n;
+  const int ncu = md_device_cus();
+  const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
+  hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);
+}

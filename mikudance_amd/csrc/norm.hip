@@ -19,10 +19,12 @@
 // Statistics are the one-sweep sums of (x - k) and (x - k)^2 in fp32, k = the value of the group's FIRST channel at PIXEL 0 of
 // the image: a pilot of the group mean (a sample of the very distribution being normalised), so the sums stay O(n * sigma) and
 // var = E[(x-k)^2] - E[x-k]^2 does not cancel when |mean| >> sigma (the plain E[x^2] - mean^2 loses the variance at
-// |mean| / sigma ~ 100 in fp32).  Both kernels read k from the same element, so it is bit-identical on the two sides; it costs
-// two 2-byte loads per thread (8 when a thread's 8 channels can span more than two groups), no synchronisation.
+// |mean| / sigma ~ 100 in fp32).  The statistics sweep reads k from x (two 2-byte loads per thread, 8 when a thread's 8 channels can
+// span more than two groups) and its slab-0 workgroups hand it to the apply sweep through the workspace (bit-identical on both sides,
+// and safe when the apply sweep runs in place).
 // Thread (cc, r): channel chunk cc (8 channels), row lane r.  A block owns `slab` consecutive pixels of one image.
-__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int R, int slab, int nslab) {
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, float* __restrict__ pilot, int HW, int C, int G, int R, int slab,
+                                int nslab) {
   extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
@@ -71,10 +73,13 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     float* o = part + (((size_t)b * nslab + sl) * G + g) * 2;
     o[0] = a;
     o[1] = c2;
+    // the pilot travels through the workspace: the apply sweep may run IN PLACE (y == x) and overwrite pixel 0 before the other
+    // workgroups of the image have read it
+    if (sl == 0) pilot[(size_t)b * G + g] = (float)ximg[g * cpg];
   }
 }
 
-__global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ part, const half_t* __restrict__ gamma,
+__global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restrict__ part, const float* __restrict__ pilot, const half_t* __restrict__ gamma,
                                 const half_t* __restrict__ beta, int HW, int C, int G, int R, int slab, int nslab, float eps, int silu, int zigzag) {
   __shared__ float mean_s[64], rstd_s[64];
   const int cch = C >> 3;
@@ -93,7 +98,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     const float n = (float)HW * (float)cpg;
     const float mu = a / n;                               // mean of x - k
     const float var = fmaxf(c2 / n - mu * mu, 0.f);
-    mean_s[g] = (float)x[(size_t)b * HW * C + g * cpg] + mu;   // + the pilot
+    mean_s[g] = pilot[(size_t)b * G + g] + mu;                   // + the pilot (as the statistics sweep saw it)
     rstd_s[g] = rsqrtf(var + eps);
   }
   __syncthreads();
@@ -136,7 +141,7 @@ static void gn_geometry(int B, int HW, int C, int& R, int& slab, int& nslab) {
 extern "C" size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
   int R, slab, nslab;
   gn_geometry(B, HW, C, R, slab, nslab);
-  return (size_t)B * nslab * G * 2 * sizeof(float);
+  return ((size_t)B * nslab * G * 2 + (size_t)B * G) * sizeof(float);       // partial sums + one pilot per (image, group)
 }
 
 extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps, int silu,
@@ -153,9 +158,10 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
   static const int zigzag = md_env_int("MD_GN_ZIGZAG", 1);
   const dim3 grid(nslab, B), block(cch * R);
   const size_t sh = (size_t)2 * R * C * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, HW, C, G, R, slab, nslab);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const half_t*)gamma,
-                     (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu, zigzag);
+  float* pilot = (float*)workspace + (size_t)B * nslab * G * 2;
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, pilot, HW, C, G, R, slab, nslab);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const float*)pilot,
+                     (const half_t*)gamma, (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu, zigzag);
   MD_CHECK_LAUNCH("md_groupnorm");
   return MD_OK;
 }

@@ -148,21 +148,23 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------- matrix-core flavour, F <= 16
+// ---------------------------------------------------------------------------------------------- matrix-core flavour, F <= 32
 // The lane-per-query kernel above is VALU bound (PMC on MI355X, d = 40: VALU 90 % busy at 3.9 TB/s: ~580 VALU instructions
-// per (pixel, head)).  Here ONE WAVE owns a (pixel, head) unit and the two small products run on the matrix core:
+// per (pixel, head)).  Here ONE WAVE owns a (pixel, head) unit and the two small products run on the matrix core, in QB x QB
+// blocks of 16 keys x 16 queries (QB = 1: F <= 16, QB = 2: F <= 32 -- the 30-frame windows of BASELINE configs[4]):
 //   S^T[key][query] = K Q^T   v_mfma_f32_16x16x32_f16, A = K fragment (LDS, ds_read_b128), B = Q fragment (global -> registers,
 //                             fetched before the K/V staging is issued), ceil(D / 32) steps, k-slots past D zero filled
-//   softmax over keys         a lane holds keys 4g .. 4g+3 of query m (g = lane / 16, m = lane % 16): 3 in-lane steps + 2 lane
-//                             exchanges (xor 16, xor 32) for the maximum and for the sum
-//   O^T[d][query] = V^T P^T   v_mfma_f32_16x16x16_f16: the S^T accumulator layout IS the B operand layout (keys 4g .. 4g+3 of
-//                             query m), A = V^T tile gathered from the frame-major LDS image with 2-byte reads, ceil(D / 16) tiles
+//   softmax over keys         a lane holds keys 16 kb + 4g .. 4g+3 of query 16 qb + m (g = lane / 16, m = lane % 16): in-lane steps
+//                             + 2 lane exchanges (xor 16, xor 32) for the maximum and for the sum
+//   O^T[d][query] = V^T P^T   v_mfma_f32_16x16x16_f16 (one per key block, accumulated): the S^T accumulator layout IS the B operand
+//                             layout (keys 4g .. 4g+3 of query m), A = V^T tile gathered from the frame-major LDS image with 2-byte
+//                             reads, ceil(D / 16) tiles
 // Frames >= F are clamped for the loads, masked as keys (-inf) and not stored as queries.  The LDS image keeps the DMA's lane
 // linear order but every frame row carries one extra 16-byte slot, so the 16 frame rows a fragment read touches start 16 bytes
 // apart modulo the 256-byte bank period (unpadded rows of PB * HG * D * 2 = 1280 bytes would all start in the same bank).
-template <int D>
+template <int D, int QB>
 __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams p) {
-  constexpr int NKS = (D + 31) / 32, NT = (D + 15) / 16, MAXU = 4;
+  constexpr int NKS = (D + 31) / 32, NT = (D + 15) / 16, MAXU = QB == 1 ? 4 : 2;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,24 +176,29 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
   const int npix = p.NB * p.HW;
   const int col0 = grp * CW;
   const int m = lane & 15, g = lane >> 4;
-  const int fm = min(m, p.F - 1);
+  int fm[QB];                                          // frame of this lane's query (B operand column) / key (A operand row) per block
+#pragma unroll
+  for (int b = 0; b < QB; ++b) fm[b] = min(16 * b + m, p.F - 1);
   const int nunit = p.PB * p.HG;                       // <= 4 * MAXU (launcher); wave w owns units w, w + 4, ...
 
   // ---- Q fragments of this wave's units: global -> registers, in flight while K / V are staged
-  half8_t qf[MAXU][NKS];
+  half8_t qf[MAXU][QB][NKS];
 #pragma unroll
   for (int u = 0; u < MAXU; ++u) {
     const int unit = min(wave + 4 * u, nunit - 1);
     const int pl = unit / p.HG, hl = unit - pl * p.HG;
     const int gp = min(pg + pl, npix - 1);
     const int b = gp / p.HW, pix = gp - b * p.HW;
-    const size_t row = ((size_t)b * p.F + fm) * p.HW + pix;
-    const half_t* qp = p.Q + row * p.ldq + col0 + hl * D + 8 * g;
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (32 * s + 8 * g < D) v = *reinterpret_cast<const half8_t*>(qp + 32 * s);
-      qf[u][s] = v;
+    for (int qb = 0; qb < QB; ++qb) {
+      const size_t row = ((size_t)b * p.F + fm[qb]) * p.HW + pix;
+      const half_t* qp = p.Q + row * p.ldq + col0 + hl * D + 8 * g;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (32 * s + 8 * g < D) v = *reinterpret_cast<const half8_t*>(qp + 32 * s);
+        qf[u][qb][s] = v;
+      }
     }
   }
 
@@ -228,74 +235,107 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
     const int gp = pg + pl;
     if (gp >= npix) break;
     const int ubase = (pl * CW + hl * D) * 2;          // byte offset of this unit's columns inside a frame row
-    // ---- S^T = K Q^T
-    floatx4 sacc = {0.f, 0.f, 0.f, 0.f};
+    // ---- S^T = K Q^T, QB x QB blocks
+    floatx4 sacc[QB][QB];
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) sacc[kb][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
-      half8_t kf = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (32 * s + 8 * g < D) kf = *reinterpret_cast<const half8_t*>(Ks + fm * RS + ubase + (32 * s + 8 * g) * 2);
-      sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][s], sacc, 0, 0, 0);
-    }
-    // ---- softmax over the keys 4g + r of query m
-    float sv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sv[r] = (4 * g + r < p.F) ? sacc[r] * p.scale_log2 : -1.0e30f;
-    float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-    mx = fmaxf(mx, xch(x16, mx));
-    mx = fmaxf(mx, xch(x32, mx));
-    float l = 0.f;
-    half4_t pb;
+      for (int kb = 0; kb < QB; ++kb) {
+        half8_t kf = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (32 * s + 8 * g < D) kf = *reinterpret_cast<const half8_t*>(Ks + fm[kb] * RS + ubase + (32 * s + 8 * g) * 2);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = __builtin_amdgcn_exp2f(sv[r] - mx);   // masked keys: exp2(-huge) = 0
-      l += e;
-      pb[r] = (half_t)e;
+        for (int qb = 0; qb < QB; ++qb) sacc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][qb][s], sacc[kb][qb], 0, 0, 0);
+      }
     }
-    l += xch(x16, l);
-    l += xch(x32, l);
-    const float inv = 1.f / l;
+    // ---- softmax over the keys 16 kb + 4g + r of query 16 qb + m
+    half4_t pb[QB][QB];                                 // [qb][kb]
+    float inv[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float sv[QB][4];
+      float mx = -1.0e30f;
+#pragma unroll
+      for (int kb = 0; kb < QB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[kb][r] = (16 * kb + 4 * g + r < p.F) ? sacc[kb][qb][r] * p.scale_log2 : -1.0e30f;
+          mx = fmaxf(mx, sv[kb][r]);
+        }
+      mx = fmaxf(mx, xch(x16, mx));
+      mx = fmaxf(mx, xch(x32, mx));
+      float l = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < QB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sv[kb][r] - mx);   // masked keys: exp2(-huge) = 0
+          l += e;
+          pb[qb][kb][r] = (half_t)e;
+        }
+      l += xch(x16, l);
+      l += xch(x32, l);
+      inv[qb] = 1.f / l;
+    }
     // ---- O^T = V^T P^T, 16 rows of d per tile
     const int ob = gp / p.HW, opix = gp - ob * p.HW;
-    const size_t orow = ((size_t)ob * p.F + fm) * p.HW + opix;
-    half_t* op = p.O + orow * p.ldo + col0 + hl * D;
-    const half_t* vcol = reinterpret_cast<const half_t*>(Vs + ubase);
-    int vrow[4];
+    half_t* op[QB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vrow[i] = min(4 * g + i, p.F - 1) * (RS >> 1);
+    for (int qb = 0; qb < QB; ++qb) op[qb] = p.O + (((size_t)ob * p.F + fm[qb]) * p.HW + opix) * p.ldo + col0 + hl * D;
+    const half_t* vcol = reinterpret_cast<const half_t*>(Vs + ubase);
+    int vrow[QB][4];
+#pragma unroll
+    for (int kb = 0; kb < QB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vrow[kb][i] = min(16 * kb + 4 * g + i, p.F - 1) * (RS >> 1);
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int dc = 16 * tt + m;
-      half4_t vf = {0, 0, 0, 0};
-      if (dc < D) {
+      half4_t vf[QB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vf[i] = vcol[vrow[i] + dc];
+      for (int kb = 0; kb < QB; ++kb) {
+        vf[kb] = half4_t{0, 0, 0, 0};
+        if (dc < D) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) vf[kb][i] = vcol[vrow[kb][i] + dc];
+        }
       }
-      floatx4 o = {0.f, 0.f, 0.f, 0.f};
-      o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pb, o, 0, 0, 0);
-      const int db = 16 * tt + 4 * g;                  // o[r] = O[query m][d = db + r]
-      if (m < p.F && db < D) {
-        const half4_t ov = {(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
-        *reinterpret_cast<half4_t*>(op + db) = ov;
+      const int db = 16 * tt + 4 * g;                  // o[r] = O[query 16 qb + m][d = db + r]
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        floatx4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < QB; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[kb], pb[qb][kb], o, 0, 0, 0);
+        if (16 * qb + m < p.F && db < D) {
+          const half4_t ov = {(half_t)(o[0] * inv[qb]), (half_t)(o[1] * inv[qb]), (half_t)(o[2] * inv[qb]), (half_t)(o[3] * inv[qb])};
+          *reinterpret_cast<half4_t*>(op[qb] + db) = ov;
+        }
       }
     }
   }
 }
 
-template <int D>
+template <int D, int QB>
 static void launch_temporal_mfma(TemporalParams p, hipStream_t st) {
-  // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds 48 KiB; then as
-  // many pixels as fit in 48 KiB, at most 16 (pixel, head) units (4 per wave)
-  static const size_t cap = (size_t)md_env_int("MD_TEMPORAL_LDS_KB", 48) * 1024;
+  // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds the LDS budget
+  // (48 KiB for F <= 16, swept 24 .. 90; 80 KiB for the 17 .. 32-frame windows, whose images are twice as tall); then as many
+  // pixels as fit, at most 4 * MAXU (pixel, head) units (MAXU = 4 / 2 per wave)
+  static const size_t cap1 = (size_t)md_env_int("MD_TEMPORAL_LDS_KB", 48) * 1024;
+  const size_t cap = QB == 1 ? cap1 : (size_t)80 * 1024;
+  constexpr int UNITS = QB == 1 ? 16 : 8;
   int HG = p.H;
   auto lds = [&](int hg, int pb) { return (size_t)2 * ((((size_t)p.F * (pb * hg * D * 2 + 16)) + 1023) / 1024 * 1024); };
   while (HG > 1 && lds(HG, 1) > cap) HG >>= 1;
-  int PB = 16 / HG;
+  int PB = UNITS / HG;
   while (PB > 1 && lds(HG, PB) > cap) --PB;
   p.HG = HG; p.PB = PB;
   const size_t smem = lds(HG, PB);
   const int grid = cdiv((long)p.NB * p.HW, PB) * (p.H / HG);
-  md_ensure_dynamic_lds<temporal_attn_mfma_kernel<D>>(96 * 1024);
-  hipLaunchKernelGGL(temporal_attn_mfma_kernel<D>, dim3(grid), dim3(256), smem, st, p);
+  md_ensure_dynamic_lds<temporal_attn_mfma_kernel<D, QB>>(96 * 1024);
+  hipLaunchKernelGGL((temporal_attn_mfma_kernel<D, QB>), dim3(grid), dim3(256), smem, st, p);
 }
 
 template <int FMAX, int NCH>
@@ -324,10 +364,18 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
   p.NB = NB; p.F = F; p.HW = HW; p.H = H; p.D = D;
   p.scale_log2 = scale * 1.4426950408889634f;
   static const int use_mfma = md_env_int("MD_TEMPORAL_MFMA", 1);   // 0: lane-per-query kernel for every shape (A/B)
-  if (use_mfma && F <= 16 && (D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31)) {
-    if (D == 40) launch_temporal_mfma<40>(p, (hipStream_t)stream);
-    else if (D == 80) launch_temporal_mfma<80>(p, (hipStream_t)stream);
-    else launch_temporal_mfma<160>(p, (hipStream_t)stream);
+  static const int mfma32 = md_env_int("MD_TEMPORAL_MFMA32", 1);   // 0: windows of 17 .. 32 frames stay on the lane-per-query kernel (A/B)
+  if (use_mfma && (F <= 16 || mfma32) && (D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (F <= 16) {
+      if (D == 40) launch_temporal_mfma<40, 1>(p, st);
+      else if (D == 80) launch_temporal_mfma<80, 1>(p, st);
+      else launch_temporal_mfma<160, 1>(p, st);
+    } else {
+      if (D == 40) launch_temporal_mfma<40, 2>(p, st);
+      else if (D == 80) launch_temporal_mfma<80, 2>(p, st);
+      else launch_temporal_mfma<160, 2>(p, st);
+    }
     MD_CHECK_LAUNCH("md_temporal_attention_fwd");
     return MD_OK;
   }

@@ -14,6 +14,7 @@ G4 UNets        : reference glue (unet_2d_mix / unet_3d_mix / mutual_mix_attenti
 G5 loop         : the loop of src/pipelines/pipeline_mikudance.py:573-686 driven with the reference UNets,
                   ReferenceAttentionControl and context scheduler; DDIM is the restated scheduler (third party)
 G6 keys         : full-size state-dict key -> shape maps of both UNets (checkpoint-compat contract)
+G13 no-CFG loop : the same loop with guidance_scale = 1 (one clip-half, every row reads the bank, window SUM not average)
 """
 import json
 import os
@@ -334,6 +335,54 @@ def g12_interpolation():
     save_file({k: x.contiguous() for k, x in t.items()}, os.path.join(OUT, "g12_interpolation.safetensors"))
 
 
+def g13_no_cfg_loop():
+    """guidance_scale <= 1 (pipeline_mikudance.py:397): no classifier-free guidance.  The reference then builds ONE clip-half
+    (:626-645: `.repeat(1, ...)`), keeps the CLIP tokens alone as context (:420-423), constructs ReferenceAttentionControl with
+    do_classifier_free_guidance=False (every row reads the bank, mutual_mix_attention.py:181-201) and -- the division sits
+    inside `if do_classifier_free_guidance:` (:670-674) -- feeds the scheduler the window SUM, not the window average.
+    3 steps, F = 6, context 4, overlap 2 (wrapping windows, frames covered twice), small geometry, same weights as G4 / G5."""
+    from src.models.mutual_mix_attention import ReferenceAttentionControl
+    from src.pipelines.context import get_context_scheduler
+    ref, den, ref_sd, den_sd = build_unets(**SMALL)
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=False, mode="write", batch_size=1, fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=False, mode="read", batch_size=1, fusion_blocks="full")
+    F_, h, w = 6, 16, 16
+    latents, ref_latents, embeds = synth_inputs(F_, h, w, ctx_len=5, ctx_dim=64, seed=100)
+    image_prompt_embeds = embeds[1:]                                  # the conditional tokens alone
+    t = {}
+    sch = DDIM()
+    steps, gs = 3, 1.0
+    do_cfg = gs > 1.0
+    timesteps = sch.set_timesteps(steps)
+    sched = get_context_scheduler("uniform")
+    lat = latents.clone()
+    for t_ in timesteps:
+        noise_pred = torch.zeros((lat.shape[0] * (2 if do_cfg else 1),) + tuple(lat.shape[1:]))
+        counter = torch.zeros((1, 1, F_, 1, 1))
+        queue = list(sched(0, steps, F_, 4, 1, 2))
+        for c in queue:
+            lmi = torch.cat([lat[:, :, c]]).repeat(2 if do_cfg else 1, 1, 1, 1, 1)
+            b, cc, f, hh, ww = lmi.shape
+            rli = torch.cat([ref_latents[:, c]]).repeat(2 if do_cfg else 1, 1, 1, 1, 1).reshape(b * f, 22, hh, ww)
+            emb_in = image_prompt_embeds.repeat((f, 1, 1))
+            ref(rli, torch.zeros_like(t_), encoder_hidden_states=emb_in, return_dict=False)
+            reader.update(writer)
+            pred = den(lmi, t_, encoder_hidden_states=emb_in[:b], return_dict=False)[0]
+            noise_pred[:, :, c] = noise_pred[:, :, c] + pred
+            counter[:, :, c] = counter[:, :, c] + 1
+            reader.clear(); writer.clear()
+        if do_cfg:
+            u, c_ = (noise_pred / counter).chunk(2)
+            noise_pred = u + gs * (c_ - u)
+        lat = sch.step(noise_pred, t_, lat)
+        t[f"g13.latents_after_t{int(t_)}"] = lat.clone()
+    assert float(counter.max()) > 1.0                                 # the windows really overlap
+    save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(OUT, "g13_no_cfg_loop.safetensors"))
+    json.dump({"frames": F_, "context_frames": 4, "overlap": 2, "steps": steps, "guidance": gs, "timesteps": [int(x) for x in timesteps],
+               "windows": [list(map(int, c)) for c in queue], "seed_inputs": 100, "seed_den": 1234, "seed_ref": 4321,
+               "checksum_den": checksum(den_sd)}, open(os.path.join(OUT, "g13_meta.json"), "w"))
+
+
 def g6_keys():
     ref, den, _, _ = build_unets()      # full SD-1.5 geometry (constructor defaults + cross_attention_dim 768)
     json.dump({"denoising_unet": {k: list(v.shape) for k, v in den.state_dict().items()},
@@ -353,7 +402,7 @@ def g7_ddim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     if "g1" in which: g1_windows()
     if "g2" in which: g2_scene_motion()
     if "g3" in which: g3_blocks()
@@ -365,5 +414,6 @@ if __name__ == "__main__":
     if "g10" in which: g10_odd_and_plain_gn()
     if "g11" in which: g11_clip()
     if "g12" in which: g12_interpolation()
+    if "g13" in which: g13_no_cfg_loop()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

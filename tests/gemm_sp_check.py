@@ -1,0 +1,98 @@
+"""Parity + race screen of the one-wave-per-SIMD GEMM / conv flavour (gemm_sp.h).  Run as a script with MD_GEMM_SP=1 (the dispatch
+override is read once per process, so tests/test_gemm_sp_gpu.py spawns this file); every case goes through the C ABI and is
+compared with an fp32 PyTorch evaluation of the same fp16-rounded operands: |err| <= 1e-2 * maxabs(ref) + 1e-3.  Each case
+is also run three times and must be bit-identical run to run (an LDS ring race shows up as run-to-run differences)."""
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mikudance_amd import ops, packing  # noqa: E402
+
+assert os.environ.get("MD_GEMM_SP") == "1", "run with MD_GEMM_SP=1"
+dev = torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+def check(what, fn, ref, rtol=1e-2, atol=1e-3):
+    outs = [fn() for _ in range(3)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), f"{what}: not deterministic run to run"
+    got, ref = outs[0].float().cpu(), ref.float()
+    err = (got - ref).abs().max().item()
+    bound = rtol * ref.abs().max().item() + atol
+    assert math.isfinite(err) and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+    print(f"ok  {what}: err {err:.3g} (bound {bound:.3g})")
+
+
+d = lambda t: t.to(dev)
+
+# plain GEMM, N % 320 == 0: K from 4 ring tiles (the ring depth) to 90, ragged M, several column tiles; the last two give the
+# persistent kernel 2-3 output tiles per workgroup (57 600 / 192 = 300 tiles, 100 000 / 192 -> 521 tiles, ragged)
+for M, N, K in [(256, 320, 128), (1000, 320, 192), (77, 640, 256), (2048, 320, 320), (700, 1280, 1280), (4096, 640, 2880),
+                (57600, 320, 256), (100000, 320, 160)]:
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    check(f"gemm {M}x{N}x{K}", lambda: ops.gemm(d(a), d(w)), a.float() @ w.float().t())
+
+# identity: exact, catches fragment / row / column mix-ups in the 96x160 wave tile
+K = 320
+a = torch.eye(K).half()
+w = (torch.arange(K * K).reshape(K, K) % 97).half() / 16
+out = ops.gemm(d(a), d(w))
+assert torch.equal(out.cpu().float(), w.float().t()), "identity"
+print("ok  identity")
+
+# epilogues
+M, N, K = 900, 640, 256
+a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+bias, res, radd = rnd(N, seed=5), rnd(M, N, seed=6), rnd(9, N, seed=7)
+base = a.float() @ w.float().t() + bias.float()
+check("bias", lambda: ops.gemm(d(a), d(w), bias=d(bias)), base)
+check("silu", lambda: ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_SILU), F.silu(base))
+check("relu", lambda: ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_RELU), F.relu(base))
+check("residual", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(res)), base + res.float())
+check("rowadd", lambda: ops.gemm(d(a), d(w), bias=d(bias), rowadd=d(radd), rows_per_group=100),
+      base + radd.float().repeat_interleave(100, 0))
+res_dev = d(res).clone()
+hs = res_dev.clone()
+ops.gemm(d(a), d(w), bias=d(bias), residual=hs, out=hs)                     # in place (blocks.py cross-attention)
+check("residual in place", lambda: hs, base + res.float())
+wide = rnd(M, 2 * K, seed=8)
+check("lda", lambda: ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t())
+
+# GEGLU (256 x 256 tiles; the last two cases give the persistent kernel 2-3 output tiles per workgroup, one of them ragged in M)
+for M, K, inner in [(200, 128, 256), (1500, 320, 1280), (300, 1280, 512), (10240, 128, 1024), (20000, 320, 1024)]:
+    a = rnd(M, K, seed=11)
+    w, b = rnd(2 * inner, K, seed=12, scale=K ** -0.5), rnd(2 * inner, seed=13)
+    hg = a.float() @ w.float().t() + b.float()
+    wp, bp = packing.geglu_weight(w, b, dev)
+    check(f"geglu {M}x{2 * inner}x{K}", lambda: ops.gemm(d(a), wp, bias=bp, act=ops.ACT_GEGLU), hg[:, :inner] * F.gelu(hg[:, inner:]))
+
+# 3x3 convolutions with Cout % 320 == 0: padding, stride 2, folded 2x upsample, fused time embedding + residual
+for cin, cout, h, wd, stride, up in [(64, 320, 8, 8, 1, False), (320, 320, 24, 24, 1, False), (128, 640, 13, 11, 2, False),
+                                     (64, 320, 6, 5, 1, True), (640, 320, 16, 16, 1, False), (64, 320, 96, 96, 1, False)]:
+    B = 8 if h == 96 else 3      # 96 x 96 x 8 = 384 output tiles: the persistent kernel wraps
+    x = rnd(B, cin, h, wd, seed=20)
+    wt = rnd(cout, cin, 3, 3, seed=21, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=22)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, wt.float(), bias.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wpk = packing.conv3x3_weight(wt, dev)
+    check(f"conv {cin}->{cout} {h}x{wd} s{stride} up{int(up)}", lambda: ops.conv3x3(d(xn), wpk, cout, bias=d(bias), stride=stride, upsample=up), ref)
+B, c, h, wd = 4, 320, 8, 8
+x, wt, bias = rnd(B, h, wd, c, seed=23), rnd(c, c, 3, 3, seed=24, scale=(9 * c) ** -0.5), rnd(c, seed=25)
+temb, res = rnd(2, c, seed=26), rnd(B, h, wd, c, seed=27)
+ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+ref = ref + temb.float().repeat_interleave(2, 0)[:, None, None, :] + res.float()
+wpk = packing.conv3x3_weight(wt, dev)
+check("conv+temb+res", lambda: ops.conv3x3(d(x), wpk, c, bias=d(bias), residual=d(res), rowadd=d(temb), rows_per_group=2 * h * wd), ref)
+print("ALL OK")

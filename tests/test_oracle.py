@@ -115,6 +115,26 @@ def test_g5_loop_literal_and_reduced(small):
         assert rel(got[True][ts], got[False][ts]) < 1e-5, ts
 
 
+def test_g13_no_cfg_loop_literal_and_reduced(small, golden_dir):
+    """guidance_scale = 1 (no classifier-free guidance): one clip-half, every row reads the bank, and the window SUM (not the
+    average) goes to the scheduler -- against the loop driven with the reference's own modules (oracle/gen_golden.py g13)."""
+    meta, ref_sd, den_sd, t = small
+    g13 = json.load(open(os.path.join(golden_dir, "g13_meta.json")))
+    gold = load_file(os.path.join(golden_dir, "g13_no_cfg_loop.safetensors"))
+    assert abs(g13["checksum_den"] - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
+    got = {}
+    with torch.no_grad():
+        for reduced in (False, True):
+            snaps = {}
+            O.denoise_loop(ref_sd, den_sd, t["in.latents"], t["in.ref_latents"], t["in.embeds"][1:], g13["steps"],
+                           guidance_scale=g13["guidance"], context_frames=g13["context_frames"], context_stride=1,
+                           context_overlap=g13["overlap"], reduced=reduced, on_step=lambda ts, lat: snaps.__setitem__(ts, lat.clone()))
+            got[reduced] = snaps
+    for ts in g13["timesteps"]:
+        assert rel(got[False][ts], gold[f"g13.latents_after_t{ts}"]) < 2e-4, ts
+        assert rel(got[True][ts], got[False][ts]) < 1e-5, ts
+
+
 def test_g8_full_width_oracle_vs_reference(golden_dir):
     """The restatement at FULL WIDTH (SD-1.5 geometry, head dims 40/80/160, 257x768 context) against the prediction of
     the reference's own modules at configs[0] shape (oracle/gen_golden.py g8)."""

@@ -76,13 +76,41 @@ def test_g5_loop_vs_reference_golden(small, reuse):
     assert rel_l2(out.float(), last) < 3e-2
 
 
-def test_loop_no_cfg_and_single_window_vs_oracle(small):
+def test_loop_single_window_vs_oracle(small):
+    """One window covering the clip (F = 4 <= context_frames), with guidance."""
     meta, ref, den, ref_sd, den_sd, t = small
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     lat, rl, emb = t["in.latents"][:, :, :4], t["in.ref_latents"][:, :4], t["in.embeds"]
     with torch.no_grad():
         want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 3, guidance_scale=3.5, reduced=True)
     out = pipe.denoise(lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 3, 3.5)
+    assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_g13_no_cfg_loop_vs_reference_golden(small, golden_dir, reuse):
+    """guidance_scale = 1.0 switches classifier-free guidance off (reference src/pipelines/pipeline_mikudance.py:397): one
+    clip-half (nb = 1), the CLIP tokens alone as context, every row of the denoising UNet reads the bank
+    (mutual_mix_attention.py:181-201 without the CFG mask) and the window SUM -- not the average -- goes to the scheduler (the
+    division by the counter sits inside `if do_classifier_free_guidance:`, :670-674).  Against the loop driven with the
+    reference's own modules (tests/golden/g13_*, oracle/gen_golden.py g13; wrapping windows, frames covered twice) and the oracle."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    g13 = json.load(open(os.path.join(golden_dir, "g13_meta.json")))
+    gold = load_file(os.path.join(golden_dir, "g13_no_cfg_loop.safetensors"))
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    pipe.reference_reuse = reuse
+    snaps = {}
+    emb = t["in.embeds"][1:]
+    out = pipe.denoise(t["in.latents"].cuda().half(), t["in.ref_latents"].cuda().half(), emb.cuda().half(), g13["steps"],
+                       g13["guidance"], context_frames=g13["context_frames"], context_stride=1, context_overlap=g13["overlap"],
+                       callback=lambda i, ts, lat: snaps.__setitem__(ts, lat.float().cpu()))
+    for ts in g13["timesteps"]:
+        want = gold[f"g13.latents_after_t{ts}"]
+        r, c = rel_l2(snaps[ts], want), cosine(snaps[ts], want)
+        assert r < 3e-2 and c > 0.999, (ts, r, c)
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, t["in.latents"], t["in.ref_latents"], emb, g13["steps"], guidance_scale=1.0,
+                              context_frames=g13["context_frames"], context_overlap=g13["overlap"], reduced=True)
     assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
 
 
