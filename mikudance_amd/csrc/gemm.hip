@@ -46,6 +46,7 @@ struct GemmParams {
   // conv
   int Hin, Win, Cin, Hout, Wout, stride, upsample, pad;   // pad: zero rows/cols before the image (1, or 0 for the VAE downsampler)
   int tiles_n, tiles_total;
+  int tiles_m, group_m;   // gemm_sp_kernel: tile order (group_m row panels of tiles are walked column by column)
 };
 
 __device__ __attribute__((aligned(64))) half_t g_zero_page[32] = {};
@@ -557,9 +558,16 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   static const int narrow = env_int("MD_GEMM_NARROW", 0);
   static const int pp = env_int("MD_GEMM_PP", 2);          // 0: off, 1: every eligible problem, 2: automatic
   static const int sp = env_int("MD_GEMM_SP", 0);          // one-wave-per-SIMD flavour (gemm_sp.h): 0 off, 1 every eligible problem, 2 automatic
-  if (sp == 1 && sp_eligible<CONV, GEGLU>(p)) {
-    launch_sp<CONV, GEGLU>(p, stream);
-    return;
+  if (sp > 0 && sp_eligible<CONV, GEGLU>(p)) {
+    // automatic rule from the same-box A/B on MI355X (profiles/r03_ab_gemm_sp.log): every 3x3 conv with at least 192 tiles of
+    // 192 x 320 (+5..22 %), GEGLU GEMMs with K >= 640 (+4..6 %), plain GEMMs with K >= 2560 (+5..14 %); the short-K projections
+    // stay on the streaming kernel, the M = 18 432 x N = 1280 shapes (1.5 rounds of tiles) on the 128 x 128 kernel
+    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : 192) * (p.N / (GEGLU ? 256 : 320));
+    const bool pick = CONV ? tiles >= 192 : (GEGLU ? p.K >= 640 : p.K >= 2560);
+    if (sp == 1 || pick) {
+      launch_sp<CONV, GEGLU>(p, stream);
+      return;
+    }
   }
   // ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
   // loop long enough to amortise its prologue / epilogue, which no other workgroup covers.  Same-box A/B on MI355X:

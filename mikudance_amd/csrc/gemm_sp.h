@@ -31,6 +31,9 @@
 // DMA pieces are issued unconditionally (beyond the last K tile they re-read the last tile's first columns into a ring slot
 // nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
+#ifndef SP_ABL
+#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
+#endif
 
 // zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
 __device__ __attribute__((aligned(64))) half_t g_zero_cols[16384] = {};
@@ -127,13 +130,22 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   const int ntile = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // output tiles of this workgroup
 
   auto tile_origin = [&](int i, int& m0, int& n0) {
-    // virtual workgroup id -> tile: every XCD (workgroup b runs on XCD b % 8) walks a contiguous run of tiles, n fastest, so the
-    // A row panel / W panel it re-reads stay in its private L2 (gridDim.x % 8 == 0 or gridDim.x == nwg)
+    // virtual workgroup id -> position t in the tile order: every XCD (workgroup b runs on XCD b % 8) walks a contiguous run of
+    // the order, its 32 CUs 32 consecutive positions at a time (gridDim.x % 8 == 0 or gridDim.x == nwg)
     const int v = (int)blockIdx.x + i * (int)gridDim.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    m0 = (t / p.tiles_n) * BM;
-    n0 = (t % p.tiles_n) * BN;
+    // tile order: groups of group_m row panels, walked column by column inside a group, so that the tiles the CUs of one XCD work
+    // on at the same time form a (group_m x 32 / group_m) block: they share group_m A panels AND 32 / group_m W panels through
+    // that XCD's L2.  Row-major order (group_m = 1) makes the 32 CUs stream 32 different W panels: the wide-N GEMMs then run at
+    // the fabric's ~4 TB/s, not at the matrix pipe's rate.
+    const int gsz = p.group_m * p.tiles_n;
+    const int grp = t / gsz, first = grp * p.group_m;
+    const int rows = min(p.group_m, p.tiles_m - first);
+    const int l = t - grp * gsz;
+    const int tn = l / rows;
+    m0 = (first + l - tn * rows) * BM;
+    n0 = tn * BN;
   };
 
   // ------------------------------------------------------------------ issue side (runs 3-4 K tiles ahead of the compute side)
@@ -243,14 +255,15 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       const int i = k / NT, j = k % NT;                                                                     \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FBU[j], FAU[i], (ZERO) ? floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[i][j], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
-      if (k < MT) {                                                                                         \
+      if (SP_ABL & 4) {                                                                                     \
+      } else if (k < MT) {                                                                                  \
         FAL[k < MT ? k : 0] = *reinterpret_cast<const half8_t*>((SB) + a_rd[S][k < MT ? k : 0]);            \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       } else if (k < MT + NT) {                                                                             \
         FBL[k < MT ? 0 : k - MT] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][k < MT ? 0 : k - MT]);  \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
-      if (k % 3 == 1 && k < 12) {                                                                           \
+      if (k % 3 == 1 && k < 12 && !(SP_ABL & 2)) {                                                          \
         issue_piece(DST, (PC0) + k / 3);                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
@@ -282,8 +295,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     SP_HALF(fa0, fb0, fa1, fb1, sb, 1, ZERO, (g + 3) & 3, 4)                                                \
     issue_advance();                                                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    wait_vmcnt<2 * G>(); /* this wave's pieces of tile g+1 (tiles g+2, g+3 may fly) */                      \
-    __builtin_amdgcn_s_barrier(); /* B_{g+1} */                                                             \
+    if (!(SP_ABL & 8)) wait_vmcnt<2 * G>(); /* this wave's pieces of tile g+1 (tiles g+2, g+3 may fly) */   \
+    if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier(); /* B_{g+1} */                                          \
     /* half 2: MFMA (g, k 16-31) || read (g+1, k 0-15) -> F0 || pieces 0-3 of tile g+4 -> the slot tile g has left */ \
     SP_HALF(fa1, fb1, fa0, fb0, sbn, 0, false, g & 3, 0)                                                    \
     ++g;                                                                                                    \
@@ -377,8 +390,11 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr size_t smem = (size_t)4 * (BM + BN) * 64;
   md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
+  static const int group_m = env_int("MD_GEMM_SP_GROUPM", 8);       // 1: row-major tile order (A/B)
   p.tiles_n = p.N / BN;
-  p.tiles_total = cdiv(p.M, BM) * p.tiles_n;
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_total = p.tiles_m * p.tiles_n;
+  p.group_m = group_m < 1 ? 1 : group_m;
   const int ncu = md_device_cus();
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
   hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);

@@ -36,9 +36,9 @@ def check(what, fn, ref, rtol=1e-2, atol=1e-3):
 d = lambda t: t.to(dev)
 
 # plain GEMM, N % 320 == 0: K from 4 ring tiles (the ring depth) to 90, ragged M, several column tiles; the last two give the
-# persistent kernel 2-3 output tiles per workgroup (57 600 / 192 = 300 tiles, 100 000 / 192 -> 521 tiles, ragged)
+# persistent kernel 2-3 output tiles per workgroup (57 600 / 192 = 300 tiles, 100 000 / 192 -> 521 tiles, ragged; 105 x 4 tiles in grouped order)
 for M, N, K in [(256, 320, 128), (1000, 320, 192), (77, 640, 256), (2048, 320, 320), (700, 1280, 1280), (4096, 640, 2880),
-                (57600, 320, 256), (100000, 320, 160)]:
+                (57600, 320, 256), (100000, 320, 192), (20000, 1280, 128)]:
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     check(f"gemm {M}x{N}x{K}", lambda: ops.gemm(d(a), d(w)), a.float() @ w.float().t())
 

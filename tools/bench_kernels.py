@@ -63,6 +63,23 @@ def main(which):
             o = torch.empty((B, H, H, Cout), device=dev, dtype=torch.float16)
             ms = timeit(lambda: ops.conv3x3(x, w, Cout, bias=b, out=o))
             out[f"conv {B}x{H}x{H} {Cin}->{Cout}"] = (ms, 2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9)
+    if "shapes" in which:      # every MFMA-bound GEMM / conv shape of the config-2 clip that the tiled kernels compete for (dispatch table)
+        for M, N, K, geglu in [(18432, 3840, 1280, False), (18432, 2560, 1280, False), (18432, 1280, 2560, False), (73728, 640, 1920, False),
+                               (294912, 320, 960, False), (294912, 320, 640, False), (73728, 1280, 640, False), (73728, 1920, 640, False),
+                               (4608, 1280, 1280, False), (4608, 10240, 1280, True), (4608, 1280, 5120, False), (4608, 2560, 1280, False)]:
+            a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+            res = rnd(M, N) if not geglu else None
+            o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=res, act=ops.ACT_GEGLU if geglu else 0, out=o))
+            out[f"gemm {M}x{N}x{K}{' geglu' if geglu else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9)
+        for B, H, Cin, Cout, st, up in [(32, 96, 960, 320, 1, False), (32, 48, 1920, 640, 1, False), (32, 48, 960, 640, 1, False), (32, 24, 1920, 1280, 1, False),
+                                        (32, 24, 640, 1280, 1, False), (32, 48, 320, 640, 1, False), (32, 12, 1280, 1280, 1, False), (32, 12, 2560, 1280, 1, False),
+                                        (32, 48, 640, 640, 1, True), (32, 24, 1280, 1280, 1, True), (32, 12, 1280, 1280, 1, True),
+                                        (32, 96, 320, 320, 2, False), (32, 48, 640, 640, 2, False), (32, 24, 1280, 1280, 2, False)]:
+            x, w, b = rnd(B, H, H, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5), rnd(Cout)
+            ms = timeit(lambda: ops.conv3x3(x, w, Cout, bias=b, stride=st, upsample=up))
+            ho = H * 2 if up else (H + 1) // st if st == 2 else H
+            out[f"conv {B}x{H}x{H} {Cin}->{Cout} s{st} up{int(up)}"] = (ms, 2.0 * B * ho * ho * Cout * 9 * Cin / ms / 1e9)
     if "conv" in which:
         for B, H, Cin, Cout in [(32, 96, 320, 320), (32, 48, 640, 640), (32, 24, 1280, 1280), (32, 24, 2560, 1280), (32, 96, 640, 320),
                                 (32, 48, 1280, 640)]:
