@@ -27,7 +27,6 @@ struct AttnParams {
   int ldq, ldk, ldvt, ldo;
   int B, H, Lq, Lk, kv_stride;
   float scale_log2;
-  int dbg;           // experiment knob of the ping-pong flavour (attention_v3.h), 0 in production
 };
 
 #define KT 64
@@ -213,26 +212,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 }
 
 #include "attention_v2.h"
-#include "attention_v3.h"
 #include "attention_v2s.h"
 #include <stdlib.h>
 
 template <int D>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
   // fast path: 16-byte aligned K / V^T key chunks (DMA granularity) and a readable pad up to the next multiple of 8 keys
-  static const int force_v1 = getenv("MD_ATTN_V1") ? 1 : 0;
-  const bool fast = !force_v1 && p.ldvt % 8 == 0 && p.kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(p.Vt) & 15) == 0 &&
+  const bool fast = p.ldvt % 8 == 0 && p.kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(p.Vt) & 15) == 0 &&
                     ((p.Lk + 7) & ~7) <= p.kv_stride;
   if constexpr (D == 40) {
-    // long self / mixed attention of the 96x96 level: ping-pong flavour (attention_v3.h), MD_ATTN_PP = 0 | 1
-    static const int pp = md_env_int("MD_ATTN_PP", 0);
-    if (fast && pp && p.Lk % A2_KT == 0 && p.Lk >= 2 * A2_KT && p.Lq >= 1024) return launch_attn3<D>(p, stream);
-  }
-  if constexpr (D == 40 || D == 80) {
-    // cross-attention (a handful of key tiles): K / V^T resident in LDS, persistent walk over the q-blocks (attention_v2s.h);
-    // opt-in until validated on hardware
-    static const int small = md_env_int("MD_ATTN_SMALL", 0);
-    if (fast && small && attn2s_eligible<D>(p)) return launch_attn2s<D>(p, stream);
+    // cross-attention at d = 40 (257 CLIP tokens = a handful of key tiles, Lq >= 2048): K / V^T resident in LDS, persistent walk
+    // over the q-blocks (attention_v2s.h).  Same-box A/B on MI355X (profiles/r03_ab_attention_small.log): Lq = 9216 0.33-0.34 ->
+    // 0.25-0.27 ms; d = 80 / 160 measured 2 % slower than the ring kernel and stay there.
+    if (fast && attn2s_eligible<D>(p)) return launch_attn2s<D>(p, stream);
   }
   if (fast) return launch_attn2<D>(p, stream);
   constexpr int KS = (D + 15) / 16, DQ = KS * 16, DVT = (D + 31) / 32;
@@ -256,7 +248,6 @@ extern "C" int md_attention_fwd_f16(const void* Q, int ldq, const void* K, int l
   p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.kv_stride = kv_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
-  p.dbg = 0;
   hipStream_t st = (hipStream_t)stream;
   switch (D) {
     case 8: return launch_attn<8>(p, st);

@@ -479,19 +479,11 @@ static int launch_attn2_qt(const AttnParams& p, hipStream_t stream) {
 
 template <int D>
 static int launch_attn2(const AttnParams& p, hipStream_t stream) {
-  // two 32-row q-tiles per wave (independent softmax chains interleave with the other tile's MFMAs and every K / V^T
-  // fragment read feeds two MFMAs) when the head dim leaves the registers for it and there are enough query rows
-  static const int qt_env = md_env_int("MD_ATTN_QT", 0);
-  if constexpr (D <= 80) {
-    const bool two = qt_env == 2;   // measured slower on MI355X (1 wave/SIMD, the compiler does not interleave the chains)
-    if (two) return launch_attn2_qt<D, 2>(p, stream);
-  }
+  // Measured on MI355X (profiles/r02_ab_attention_*.log) and settled: ONE 32-row q-tile per wave (two tiles per wave leave one wave
+  // per SIMD and the compiler does not interleave the two softmax chains: -4 %); at d <= 40 long self-attention runs 8 waves per
+  // workgroup, which share each K / V^T tile (L = 9216: 8 waves 802-810 TFLOP/s, 16 waves 803, 4 waves 782).
   if constexpr (D <= 40) {
-    // long self-attention: wider workgroups share each K / V^T tile between more waves (MD_ATTN_NW = 4 | 8 | 16).  Same-box on
-    // MI355X at L = 9216: 8 waves 802-810 TFLOP/s, 16 waves 803, 4 waves 782 (two workgroups per CU still run out of phase)
-    static const int nw = md_env_int("MD_ATTN_NW", 8);
-    if (nw == 16 && p.Lq >= 2048) return launch_attn2_qt<D, 1, 16>(p, stream);
-    if (nw == 8 && p.Lq >= 1024) return launch_attn2_qt<D, 1, 8>(p, stream);
+    if (p.Lq >= 1024) return launch_attn2_qt<D, 1, 8>(p, stream);
   }
   return launch_attn2_qt<D, 1>(p, stream);
 }

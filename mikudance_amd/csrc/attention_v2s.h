@@ -1,5 +1,5 @@
 // attn2s_kernel<D>: short-key flavour of attn2_kernel (attention_v2.h) for the CROSS-attention of the UNets: Lq = H*W queries per
-// frame against the 257 (padded 264) CLIP tokens, d = 40 / 80.
+// frame against the 257 (padded 264) CLIP tokens, dispatched at d = 40 (the 96 x 96 level).
 //
 // attn2 gives such a problem one workgroup per 256 queries: constant rows, Q load, the first K / V^T DMA (~ 1-2 us before the
 // first MFMA can start) and then only five key tiles (~ 2 us of work) -- the prologue latency is never hidden and the kernel runs
@@ -9,8 +9,9 @@
 // traffic in the loop is the Q fragment load and the O store.  Math, layouts (kappa-permuted keys, swizzled V^T, ones row,
 // folded reference with the OR-based lazy-rescale test at d = 40) are those of attn2, QT = 1.
 //
-// STATUS: written after round 2's GPU budget was spent -- compiles, NOT yet run on hardware; opt-in (MD_ATTN_SMALL=1), off by
-// default.  tools/next_round_checks.sh runs the attention tests and the A/B with it switched on.
+// Validated in round 3 (every attention parity test with it switched on) and measured on MI355X against the ring kernel
+// (profiles/r03_ab_attention_small.log): d = 40, Lq = 9216: 0.33-0.34 -> 0.25-0.27 ms (+22..36 %); d = 80 (Lq = 2304) and d = 160
+// -2 %: the dispatcher uses it at d = 40 only (the template still compiles for 80).
 #pragma once
 
 template <int D>
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512, D <= 40 ? 4 : 2) void attn2s_kernel(AttnParams
 // eligibility: d = 40 / 80, all key tiles of a pair resident in <= 64 KiB (two workgroups per CU at d = 40), long query side
 template <int D>
 static bool attn2s_eligible(const AttnParams& p) {
-  if constexpr (D != 40 && D != 80) return false;
+  if constexpr (D != 40) return false;
   constexpr int DVT = (D + 31) / 32;
   constexpr int STAGE = A2_KT * D * 2 + DVT * 32 * 128;
   const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;
@@ -254,7 +255,7 @@ static bool attn2s_eligible(const AttnParams& p) {
 
 template <int D>
 static int launch_attn2s(const AttnParams& p, hipStream_t stream) {
-  if constexpr (D == 40 || D == 80) {
+  if constexpr (D == 40) {
     constexpr int DVT = (D + 31) / 32;
     constexpr int STAGE = A2_KT * D * 2 + DVT * 32 * 128;
     const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;

@@ -446,13 +446,10 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
   }
 }
 
-// ---- variants (MD_GEMM_VARIANT / MD_CONV_VARIANT env vars select the 128-row flavour, MD_GEMM_BIG the 256-row one) ----
-//   0: BK=32 x 4 stages = 64 KiB  -> 2 workgroups/CU, three 16-KiB tiles in flight each
-//   1: BK=32 x 3 stages = 48 KiB  -> 3 workgroups/CU, two tiles in flight each
-//   2: BK=64 x 2 stages = 64 KiB  -> 2 workgroups/CU, one 32-KiB tile in flight each      (default for 3x3 convs)
-//   6: BK=64 x 1 stage  = 34 KiB  -> 3 workgroups/CU (<= 168 registers), load latency covered by the other workgroups
-//      (default for Linear GEMMs: measured best on every config-2 shape, 856 TF at 8192^3)
-//   big: 256x128, BK=64 x 3 stages = 144 KiB, 8 waves, 1 workgroup/CU, two 48-KiB tiles in flight
+// ---- the gemm_kernel flavours in use (the BK = 32 rings and the 8-wave 256-row tile of round 1 measured slower and are gone) ----
+//   BK=64 x 2 stages = 64 KiB  -> 2 workgroups/CU, one 32-KiB tile in flight each      (3x3 convs)
+//   BK=64 x 1 stage  = 34 KiB  -> 3 workgroups/CU (<= 168 registers), load latency covered by the other workgroups (Linear GEMMs)
+//   256x128, BK=64 x 1 stage = 48 KiB, 4 waves x (128x64), 2 workgroups/CU               (large convs / GEGLU / deep-K GEMMs)
 template <bool CONV, bool GEGLU, int NJ, int BK, int NSTAGE, int WM = 2, int WPS = 1, int MI = 2>
 static void launch_variant(GemmParams& p, hipStream_t stream) {
   constexpr int BN = 64 * NJ;
@@ -513,9 +510,7 @@ static void launch_ws(const GemmParams& g, hipStream_t stream) {
   p.streams = 8 * p.spx;
   // one tile per barrier round (deepest DMA ring) when the launch streams A from HBM once and sits on the store path (one column
   // group); two tiles per round when several groups share A through L2 and the tile time is barrier / latency bound
-  static const int tpr = env_int("MD_GEMM_WS_TPR", 0);           // 0: automatic, 1 / 2: forced
-  const bool two = tpr == 2 || (tpr == 0 && p.groups > 1);
-  if (two) launch_ws_tpr<KS, CB, 2>(p, stream);
+  if (p.groups > 1) launch_ws_tpr<KS, CB, 2>(p, stream);
   else launch_ws_tpr<KS, CB, 1>(p, stream);
 }
 
@@ -553,49 +548,49 @@ static bool ws_eligible(const GemmParams& p) {
 
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
-  static const int variant = env_int(CONV ? "MD_CONV_VARIANT" : "MD_GEMM_VARIANT", CONV ? 2 : 6);
-  static const int big = env_int("MD_GEMM_BIG", -1);       // -1: automatic
-  static const int narrow = env_int("MD_GEMM_NARROW", 0);
-  static const int pp = env_int("MD_GEMM_PP", 2);          // 0: off, 1: every eligible problem, 2: automatic
-  static const int sp = env_int("MD_GEMM_SP", 0);          // one-wave-per-SIMD flavour (gemm_sp.h): 0 off, 1 every eligible problem, 2 automatic
-  if (sp > 0 && sp_eligible<CONV, GEGLU>(p)) {
-    // automatic rule from the same-box A/B on MI355X (profiles/r03_ab_gemm_sp.log): every 3x3 conv with at least 192 tiles of
-    // 192 x 320 (+5..22 %), GEGLU GEMMs with K >= 640 (+4..6 %), plain GEMMs with K >= 2560 (+5..14 %); the short-K projections
-    // stay on the streaming kernel, the M = 18 432 x N = 1280 shapes (1.5 rounds of tiles) on the 128 x 128 kernel
-    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : 192) * (p.N / (GEGLU ? 256 : 320));
-    const bool pick = CONV ? tiles >= 192 : (GEGLU ? p.K >= 640 : p.K >= 2560);
-    if (sp == 1 || pick) {
-      launch_sp<CONV, GEGLU>(p, stream);
-      return;
-    }
+  // Dispatch table, from same-box A/B runs on MI355X (profiles/r0*_ab_*.log).  Two knobs survive, both used by
+  // the parity tests: MD_GEMM_PP / MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).
+  static const int pp = env_int("MD_GEMM_PP", 2);
+  static const int sp = env_int("MD_GEMM_SP", 2);
+  if (sp == 1 && sp_eligible<CONV, GEGLU>(p)) {
+    launch_sp<CONV, GEGLU>(p, stream);
+    return;
   }
-  // ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
-  // loop long enough to amortise its prologue / epilogue, which no other workgroup covers.  Same-box A/B on MI355X:
-  // +25..28 % on the 96x96 convs (950-1000 TF), +16 % on M=294912 N=320 K=1280, +3..6 % on the K >= 640 GEGLU GEMMs and the
-  // 48x48 convs with K >= 5760; slower on the 24x24 / 12x12 levels (288 / 72 tiles) and on K = 320.
+  // 1. HBM-bound short-K projections on long token matrices: W-stationary streaming kernel (gemm_ws.h), plain and GEGLU (K = 320)
   if constexpr (!CONV && !GEGLU) {
-    static const int ws = env_int("MD_GEMM_WS", 2);   // 0: off, 1: K = 320, 2: K = 320 and K = 640
-    if (ws > 0 && ws_eligible(p) && (p.K == 320 || ws >= 2)) {
+    if (ws_eligible(p)) {
       if (p.K == 320) launch_ws<10, 5>(p, stream);
       else launch_ws<20, 2>(p, stream);
       return;
     }
   }
   if constexpr (!CONV && GEGLU) {
-    static const int wsg = env_int("MD_GEMM_WS_GEGLU", 1);
-    if (wsg > 0 && ws_geglu_eligible(p)) {
+    if (ws_geglu_eligible(p)) {
       launch_ws_geglu(p, stream);
       return;
     }
   }
+  // 2. one-wave-per-SIMD flavour (gemm_sp.h): every 3x3 conv with at least 192 tiles of 192 x 320 (+3..28 % over the ping-pong /
+  //    128 x 128 kernels; the 12 x 12 level's 96 tiles run 17 % slower), GEGLU GEMMs with K >= 640 (+4..16 %), plain GEMMs with
+  //    at least 512 tiles (+4..20 %) or at least 256 tiles and K >= 2560 (+5..14 %); M = 18 432 x N = 1280 x K = 1280 (384 tiles =
+  //    1.5 rounds of 256 CUs) stays on the 128 x 128 kernel (-3..-7 %)
+  if (sp > 0 && sp_eligible<CONV, GEGLU>(p)) {
+    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : 192) * (p.N / (GEGLU ? 256 : 320));
+    const bool pick = CONV ? tiles >= 192 : (GEGLU ? p.K >= 640 : (tiles >= 512 || (tiles >= 256 && p.K >= 2560)));
+    if (pick) {
+      launch_sp<CONV, GEGLU>(p, stream);
+      return;
+    }
+  }
+  // 3. ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
+  //    loop long enough to amortise its prologue / epilogue, which no other workgroup covers
   if (pp > 0 && pp_eligible<CONV, GEGLU>(p)) {
     const long tiles = (long)cdiv(p.M, 256) * (p.N / (GEGLU ? 256 : 320));
     const long rounds = (tiles + 255) / 256;
     const long fill = tiles * 100 / (rounds * 256);               // % of the CU-rounds that carry a tile
     if constexpr (GEGLU) {
       // persistent flavour (gemm_ppg_kernel): the DMA ring runs across output tiles, so short K loops pay no prologue
-      static const int persist = env_int("MD_GEMM_PP_PERSIST", 1);
-      if (persist && (pp == 1 || (tiles >= 256 && p.K >= (persist == 2 ? 256 : 640)))) {
+      if (pp == 1 || (tiles >= 256 && p.K >= 640)) {
         launch_ppg(p, stream);
         return;
       }
@@ -605,42 +600,26 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
       return;
     }
   }
+  // 4. the occupancy flavours of gemm_kernel
   if constexpr (!GEGLU) {
-    // 64-column tiles: always for N <= 64 (conv_out, N = 4).  For N = 320 (5 x 64 instead of 3 x 128, 17 % fewer MFMAs) the
-    // same-box A/B on MI355X is a wash (the 64x32 wave tile needs 1.5 LDS fragment reads per MFMA instead of 1), so that
-    // case stays opt-in (MD_GEMM_NARROW=1).
-    const int rem = p.N % 128;
-    if (p.N <= 64 || (narrow && rem > 0 && rem <= 64)) {
+    if (p.N <= 64) {                                              // 64-column tiles: conv_out (N = 4), MAN's first conv
       if (CONV) launch_variant<CONV, false, 1, 64, 2>(p, stream);
       else launch_variant<CONV, false, 1, 64, 1, 2, 3>(p, stream);
       return;
     }
   }
-  // the 256-row tile needs enough work to fill 256 CUs with ONE workgroup each and a deep K loop to amortise its ring
-  const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
-  if (big == 1 && tiles256 >= 512 && p.K >= 512) {
-    launch_variant<CONV, GEGLU, 2, 64, 3, 4>(p, stream);        // 8 waves, 64x64 per wave, 3-deep ring
-    return;
-  }
   // 256x128 tile, 4 waves x (128x64 per wave = 4x2 MFMA tiles, 8 independent accumulators), single 48-KiB stage, 2
   // workgroups/CU: 0.75 LDS fragment reads and 0.75x the DMA bytes per MFMA of the 128x128 tile.  Same-box A/B on MI355X:
-  // +5..11 % on the 3x3 convs with >= 1024 such tiles and on every GEGLU GEMM (935 TF at 8192^3), but slower on the
-  // HBM-bound skinny Linear GEMMs and on the 24x24 / 12x12 convs (too few tiles to fill 256 CUs twice).
-  // (plain Linear GEMMs: only with a deep K loop -- +6 % on M=73728 N=640 K=2560, +12 % at 8192^3)
-  if (big == 2 || (big < 0 && tiles256 >= 1024 && (CONV || GEGLU || p.K >= 2048))) {
+  // +5..11 % on the 3x3 convs with >= 1024 such tiles and on every GEGLU GEMM, but slower on the HBM-bound skinny Linear GEMMs
+  // and on the 24x24 / 12x12 convs (too few tiles to fill 256 CUs twice); plain Linear GEMMs only with a deep K loop
+  const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
+  if (tiles256 >= 1024 && (CONV || GEGLU || p.K >= 2048)) {
     launch_variant<CONV, GEGLU, 2, 64, 1, 2, 2, 4>(p, stream);
     return;
   }
-  if (big == 3 && tiles256 >= 512) {
-    launch_variant<CONV, GEGLU, 2, 32, 2, 2, 2, 4>(p, stream);  // 4 waves, 128x64 per wave, BK=32 double buffer
-    return;
-  }
-  switch (variant) {
-    case 0: launch_variant<CONV, GEGLU, 2, 32, 4>(p, stream); break;
-    case 1: launch_variant<CONV, GEGLU, 2, 32, 3>(p, stream); break;
-    case 6: launch_variant<CONV, GEGLU, 2, 64, 1, 2, 3>(p, stream); break;
-    default: launch_variant<CONV, GEGLU, 2, 64, 2>(p, stream); break;
-  }
+  // 128x128: Linear GEMMs single 32-KiB stage at 3 workgroups/CU (occupancy hides the DMA latency), 3x3 convs a 2-deep ring
+  if (CONV) launch_variant<CONV, GEGLU, 2, 64, 2>(p, stream);
+  else launch_variant<CONV, GEGLU, 2, 64, 1, 2, 3>(p, stream);
 }
 
 static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {

@@ -42,13 +42,8 @@ __device__ __forceinline__ void pp_wait_tiles(int tiles) {
   else wait_vmcnt<0>();
 }
 
-template <bool CONV, bool GEGLU, int NJ, int PM, bool DIRECT = false>
+template <bool CONV, bool GEGLU, int NJ, int PM>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
-  // DIRECT (plain epilogues only, opt-in MD_GEMM_PP_DIRECT=1, NOT validated on hardware yet): operand roles swapped as in the GEGLU
-  // flavour (acc = mfma(W, A): a lane owns output row m = .. + lane % 32 and four 4-column pieces per 32-column sub-tile) and the
-  // epilogue goes straight from the accumulators to 16-byte stores (v_permlane32_swap pairs the pieces of the two lane halves),
-  // instead of four passes through an fp32 LDS staging tile with scalar ds_writes and two workgroup barriers each.
-  static_assert(!(DIRECT && GEGLU), "DIRECT is the plain-epilogue counterpart of the GEGLU store");
   constexpr int BK = 32, NST = 4, MI = 2;
   constexpr int BM = 256, BN = 64 * NJ;
   constexpr int NW = 8, T = 512;
@@ -217,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          acc[i][j] = (GEGLU || DIRECT) ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][s], af[i][s], acc[i][j], 0, 0, 0)
+          acc[i][j] = GEGLU ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][s], af[i][s], acc[i][j], 0, 0, 0)
                                         : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
           if (PM > 0 && (n & 3) == 1 && (n >> 2) < PM) {
             __builtin_amdgcn_sched_barrier(0);
@@ -298,71 +293,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         const int m = m0 + wm * 64 + i * 32 + lc;
         const int mc = m < p.M ? m : p.M - 1;
         geglu_store32(acc[i][2 * q], acc[i][2 * q + 1], bh, bg, p.C + (size_t)mc * p.ldc + (nc >> 1), hi, m < p.M);
-      }
-    }
-    return;
-  }
-
-  if constexpr (DIRECT) {
-    // lane (lc = lane % 32, hi = lane / 32) holds, for row m, the columns 8g + 4*hi + {0..3}, g = 0..3 of each 32-column sub-tile
-    const int lc = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + lc;
-      const bool row_ok = m < p.M;
-      const int mc = row_ok ? m : p.M - 1;
-      const half_t* ra = p.rowadd ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra : nullptr;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int nc = n0 + wn * (32 * NJ) + j * 32;              // first column of this 32-column sub-tile
-        unsigned w[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = nc + 8 * g + 4 * hi;
-          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (p.bias) {
-            const half4_t bv = *reinterpret_cast<const half4_t*>(p.bias + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-          }
-          if (ra) {
-            const half4_t av = *reinterpret_cast<const half4_t*>(ra + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)av[e];
-          }
-          if (p.act == ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-          } else if (p.act == ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (p.act == ACT_QUICKGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-          }
-          if (p.residual) {
-            const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)mc * p.ldr + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          }
-          const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          __builtin_memcpy(w[g], &o, 8);
-        }
-        half_t* drow = p.C + (size_t)mc * p.ldc + nc;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          unsigned lo[2], hi2[2];
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const auto r = __builtin_amdgcn_permlane32_swap(w[2 * pr][d], w[2 * pr + 1][d], false, false);
-            lo[d] = r[0];
-            hi2[d] = r[1];
-          }
-          if (row_ok) {
-            const uint4 v4 = {lo[0], lo[1], hi2[0], hi2[1]};
-            *reinterpret_cast<uint4*>(drow + 16 * pr + 8 * hi) = v4;
-          }
-        }
       }
     }
     return;
@@ -467,30 +397,9 @@ static void launch_pp_g(GemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_pp_kernel<CONV, GEGLU, NJ, PM>), dim3(p.tiles_total), dim3(512), smem, stream, p);
 }
 
-template <bool CONV>
-static void launch_pp_direct(GemmParams& p, hipStream_t stream) {
-  constexpr int NJ = 5, BN = 64 * NJ;
-  constexpr size_t smem = (size_t)4 * (256 + BN) * 64;
-  md_ensure_dynamic_lds<gemm_pp_kernel<CONV, false, NJ, 1, true>>((int)smem);
-  p.tiles_n = p.N / BN;
-  p.tiles_total = cdiv(p.M, 256) * p.tiles_n;
-  hipLaunchKernelGGL((gemm_pp_kernel<CONV, false, NJ, 1, true>), dim3(p.tiles_total), dim3(512), smem, stream, p);
-}
-
 template <bool CONV, bool GEGLU>
 static void launch_pp(GemmParams& p, hipStream_t stream) {
-  static const int pm = env_int("MD_GEMM_PP_PM", 1);
-  if constexpr (!GEGLU) {
-    // straight-from-the-accumulators plain epilogue (see gemm_pp_kernel): opt-in until it has been validated on hardware
-    static const int direct = env_int("MD_GEMM_PP_DIRECT", 0);
-    const bool al8 = (p.ldc % 4 == 0) && (!p.residual || p.ldr % 4 == 0) && (!p.rowadd || p.ldra % 4 == 0);
-    if (direct && al8) {
-      launch_pp_direct<CONV>(p, stream);
-      return;
-    }
-  }
-  if (pm == 0) launch_pp_g<CONV, GEGLU, 0>(p, stream);
-  else launch_pp_g<CONV, GEGLU, 1>(p, stream);
+  launch_pp_g<CONV, GEGLU, 1>(p, stream);     // one DMA piece in the MFMA slot: 0-3 measured within +-2 %
 }
 
 // ------------------------------------------------------------------------------------------------ persistent GEGLU flavour

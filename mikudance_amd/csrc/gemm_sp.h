@@ -11,7 +11,7 @@
 //     rounds of 256 CUs); MT = NT = 4 -> 256 x 256 for GEGLU (h | g column pairing needs 64-column groups per wave);
 //   * the wave is software pipelined against ITSELF: the fragments of k-step u+1 are read into the other register set and
 //     the DMA pieces of the K tile 3-4 ahead are issued in the issue slots BETWEEN the MFMAs of step u (sched_group_barrier
-//     pins one ds_read_b128 behind each of the first MT + NT MFMAs and one DMA piece behind every fourth), so the matrix pipe
+//     pins one ds_read_b128 behind each of the first MT + NT MFMAs and one DMA piece behind every fourth, a different fourth for each wave), so the matrix pipe
 //     never waits for a load slot;
 //   * K tiles of 32 in a 4-deep 32-KiB LDS ring filled by direct-to-LDS DMA (three tiles in flight, counted vmcnt), ONE
 //     s_barrier per K tile (per 30-32 MFMAs of every wave);
@@ -31,6 +31,9 @@
 // DMA pieces are issued unconditionally (beyond the last K tile they re-read the last tile's first columns into a ring slot
 // nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
+#ifndef SP_STAGGER
+#define SP_STAGGER 1   // 0: every wave issues its DMA pieces behind the same MFMAs (A/B build)
+#endif
 #ifndef SP_ABL
 #define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
 #endif
@@ -263,9 +266,20 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         FBL[k < MT ? 0 : k - MT] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][k < MT ? 0 : k - MT]);  \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
-      if (k % 3 == 1 && k < 12 && !(SP_ABL & 2)) {                                                          \
-        issue_piece(DST, (PC0) + k / 3);                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      if (!(SP_ABL & 2)) {                                                                                  \
+        if (SP_STAGGER) {                                                                                   \
+          /* wave w issues its j-th piece behind MFMA min(4 j + w, last): the four waves leave the barrier together and  */ \
+          /* run in step, so pieces issued at the same k queue up behind one another in the CU's one address path        */ \
+          if (k < 16 && (k & 3) == wave) {                                                                  \
+            issue_piece(DST, (PC0) + (k >> 2));                                                             \
+          } else if (MT * NT == 15 && k == 14 && wave == 3) {                                               \
+            issue_piece(DST, (PC0) + 3);                                                                    \
+          }                                                                                                 \
+          __builtin_amdgcn_sched_barrier(0);                                                                \
+        } else if (k % 3 == 1 && k < 12) {                                                                  \
+          issue_piece(DST, (PC0) + k / 3);                                                                  \
+          __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
   }
@@ -390,11 +404,11 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr size_t smem = (size_t)4 * (BM + BN) * 64;
   md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
-  static const int group_m = env_int("MD_GEMM_SP_GROUPM", 8);       // 1: row-major tile order (A/B)
+  constexpr int group_m = 8;       // row-major order (1) measured 3-38 % slower on the wide-N shapes (profiles/r03_ab_gemm_sp.log)
   p.tiles_n = p.N / BN;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_total = p.tiles_m * p.tiles_n;
-  p.group_m = group_m < 1 ? 1 : group_m;
+  p.group_m = group_m;
   const int ncu = md_device_cus();
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
   hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);

@@ -155,7 +155,7 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
   // The apply sweep re-reads what the statistics sweep has just read, in reverse order (most recently read slabs first): +3 % at
   // C = 640, +-0 elsewhere.  Splitting the batch into chunks so that the re-read would be served from the 256-MB memory-side cache
   // was measured and is a loss at every chunk size (24 MB: 2.7x slower, 96 MB: -12 %): launch gaps and tails, no visible hit-rate gain.
-  static const int zigzag = md_env_int("MD_GN_ZIGZAG", 1);
+  const int zigzag = 1;
   const dim3 grid(nslab, B), block(cch * R);
   const size_t sh = (size_t)2 * R * C * sizeof(float);
   float* pilot = (float*)workspace + (size_t)B * nslab * G * 2;

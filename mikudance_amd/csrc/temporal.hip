@@ -323,8 +323,7 @@ static void launch_temporal_mfma(TemporalParams p, hipStream_t st) {
   // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds the LDS budget
   // (48 KiB for F <= 16, swept 24 .. 90; 80 KiB for the 17 .. 32-frame windows, whose images are twice as tall); then as many
   // pixels as fit, at most 4 * MAXU (pixel, head) units (MAXU = 4 / 2 per wave)
-  static const size_t cap1 = (size_t)md_env_int("MD_TEMPORAL_LDS_KB", 48) * 1024;
-  const size_t cap = QB == 1 ? cap1 : (size_t)80 * 1024;
+  const size_t cap = (size_t)(QB == 1 ? 48 : 80) * 1024;
   constexpr int UNITS = QB == 1 ? 16 : 8;
   int HG = p.H;
   auto lds = [&](int hg, int pb) { return (size_t)2 * ((((size_t)p.F * (pb * hg * D * 2 + 16)) + 1023) / 1024 * 1024); };
@@ -346,11 +345,8 @@ static void launch_temporal_nch(const TemporalParams& p, int grid, int threads, 
 
 template <int FMAX>
 static void launch_temporal(const TemporalParams& p, int grid, int threads, size_t smem, hipStream_t st) {
-  static const int pre = md_env_int("MD_TEMPORAL_QPRE", 1);   // 0: query chunks loaded inside the score loop (A/B)
-  if (pre && p.D == 40) launch_temporal_nch<FMAX, 5>(p, grid, threads, smem, st);
-  else if (pre && p.D == 80) launch_temporal_nch<FMAX, 10>(p, grid, threads, smem, st);
-  else if (pre && p.D == 160 && FMAX <= 16) launch_temporal_nch<FMAX, 20>(p, grid, threads, smem, st);
-  else launch_temporal_nch<FMAX, 0>(p, grid, threads, smem, st);
+  // head dims 40 / 80 / 160 run on the matrix-core kernel; this kernel serves every other D with query chunks loaded in the loop
+  launch_temporal_nch<FMAX, 0>(p, grid, threads, smem, st);
 }
 
 extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int NB, int F, int HW,
@@ -363,9 +359,7 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.NB = NB; p.F = F; p.HW = HW; p.H = H; p.D = D;
   p.scale_log2 = scale * 1.4426950408889634f;
-  static const int use_mfma = md_env_int("MD_TEMPORAL_MFMA", 1);   // 0: lane-per-query kernel for every shape (A/B)
-  static const int mfma32 = md_env_int("MD_TEMPORAL_MFMA32", 1);   // 0: windows of 17 .. 32 frames stay on the lane-per-query kernel (A/B)
-  if (use_mfma && (F <= 16 || mfma32) && (D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31)) {
+  if ((D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31)) {
     hipStream_t st = (hipStream_t)stream;
     if (F <= 16) {
       if (D == 40) launch_temporal_mfma<40, 1>(p, st);

@@ -293,17 +293,6 @@ def test_attention_long_forces_rescale(dev):
     close(out, ref, what="attn long rescale")
 
 
-def test_attention_pingpong_flavour(dev):
-    """The opt-in ping-pong flavour (attention_v3.h, MD_ATTN_PP=1; the knob is read once per process, hence the subprocess) must
-    stay parity-green on the shapes it takes: the benchmark's d = 40 self-attention and the long rescale case."""
-    import os, subprocess, sys
-    env = dict(os.environ, MD_ATTN_PP="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "benchmark_sequence_lengths or long_forces_rescale"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "5 passed" in r.stdout, r.stdout[-500:]
-
-
 def test_attention_forces_rescale(dev):
     """Online softmax: a late key dominating one query row forces the max-rescale branch (CDNA guide rule 26)."""
     B, H, D, L = 1, 8, 40, 320
