@@ -32,7 +32,7 @@
 // nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
 #ifndef SP_STAGGER
-#define SP_STAGGER 1   // 0: every wave issues its DMA pieces behind the same MFMAs (A/B build)
+#define SP_STAGGER 0   // 1: each wave issues its DMA pieces behind different MFMAs -- measured 12-15 % SLOWER (a scalar branch per MFMA gap costs more than the shared address path; profiles/r03_ab_gemm_sp_stagger.log)
 #endif
 #ifndef SP_ABL
 #define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
@@ -53,8 +53,9 @@ __device__ __forceinline__ float sp_acc(const floatx16& a, int r) {
 // Plain epilogue of one wave's (32 MT) x (32 NT) accumulator block, straight from the registers.  acc = mfma(W, A): lane
 // (lc = lane % 32, hi = lane / 32) holds, for output row mw + 32 i + lc, the columns 8 g + 4 hi + {0..3}, g = 0..3 of every
 // 32-column sub-tile j.  v_permlane32_swap pairs the 8-byte pieces of the two lane halves into 16-byte stores (guide T21) and
-// un-pairs 16-byte residual loads (same instruction: it is an involution).  act == ACT_NONE (launcher).
-template <int MT, int NT, bool RES>
+// un-pairs 16-byte residual loads (same instruction: it is an involution).  act == ACT_NONE (launcher).  AGPR: read the accumulators
+// with sp_acc (gemm_sp_kernel: 240+ accumulators pinned in the accumulator file); false: plain reads (gemm_tw_kernel).
+template <int MT, int NT, bool RES, bool AGPR = true>
 __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][NT], int mw, int nw, int lc, int hi) {
   const half_t* bias = p.bias ? p.bias : g_zero_cols;
 #pragma unroll
@@ -87,7 +88,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
         const half4_t av = *reinterpret_cast<const half4_t*>(ra + c);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = sp_acc(acc[i][j], 4 * gi + e) + (float)bv[e] + (float)av[e];
+        for (int e = 0; e < 4; ++e) v[e] = (AGPR ? sp_acc(acc[i][j], 4 * gi + e) : acc[i][j][4 * gi + e]) + (float)bv[e] + (float)av[e];
         if constexpr (RES) {
           half4_t rv;
           __builtin_memcpy(&rv, rp[gi], 8);
