@@ -483,7 +483,6 @@ static int md_device_cus() {
 #include "gemm_pp.h"
 #include "gemm_ws.h"
 #include "gemm_sp.h"
-#include "gemm_tw.h"
 
 template <int KS, int CB, int TPR, bool RES, bool RA>
 static void launch_ws_variant(const WsParams& p, hipStream_t stream) {
@@ -553,11 +552,6 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // the parity tests: MD_GEMM_PP / MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).
   static const int pp = env_int("MD_GEMM_PP", 2);
   static const int sp = env_int("MD_GEMM_SP", 2);
-  static const int tw = env_int("MD_GEMM_TW", 0);          // two free-running waves per SIMD (gemm_tw.h): same values
-  if (tw == 1 && sp_eligible<CONV, GEGLU>(p)) {
-    launch_tw<CONV, GEGLU>(p, stream);
-    return;
-  }
   if (sp == 1 && sp_eligible<CONV, GEGLU>(p)) {
     launch_sp<CONV, GEGLU>(p, stream);
     return;

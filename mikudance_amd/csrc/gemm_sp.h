@@ -11,7 +11,8 @@
 //     rounds of 256 CUs); MT = NT = 4 -> 256 x 256 for GEGLU (h | g column pairing needs 64-column groups per wave);
 //   * the wave is software pipelined against ITSELF: the fragments of k-step u+1 are read into the other register set and
 //     the DMA pieces of the K tile 3-4 ahead are issued in the issue slots BETWEEN the MFMAs of step u (sched_group_barrier
-//     pins one ds_read_b128 behind each of the first MT + NT MFMAs and one DMA piece behind every fourth, a different fourth for each wave), so the matrix pipe
+//     pins one ds_read_b128 behind each of the first MT + NT MFMAs and one DMA piece behind every third; giving each wave its own
+//     gaps for the pieces was measured 12-15 % slower: a scalar branch per gap costs more than the shared address path), so the matrix pipe
 //     never waits for a load slot;
 //   * K tiles of 32 in a 4-deep 32-KiB LDS ring filled by direct-to-LDS DMA (three tiles in flight, counted vmcnt), ONE
 //     s_barrier per K tile (per 30-32 MFMAs of every wave);
@@ -31,9 +32,6 @@
 // DMA pieces are issued unconditionally (beyond the last K tile they re-read the last tile's first columns into a ring slot
 // nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
-#ifndef SP_STAGGER
-#define SP_STAGGER 0   // 1: each wave issues its DMA pieces behind different MFMAs -- measured 12-15 % SLOWER (a scalar branch per MFMA gap costs more than the shared address path; profiles/r03_ab_gemm_sp_stagger.log)
-#endif
 #ifndef SP_ABL
 #define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
 #endif
@@ -153,9 +151,30 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   };
 
   // ------------------------------------------------------------------ issue side (runs 3-4 K tiles ahead of the compute side)
-  const half_t* a_src[PA];
-  const half_t* w_src[PB];
-  int a_oy[PA], a_ox[PA];
+  // A piece is ONE `buffer_load_dwordx4 ... offen lds`: buffer descriptor (SGPRs) + per-lane byte offset (one VGPR, constant per
+  // output tile -- per filter tap for a conv) + the K offset of the tile as the instruction's SCALAR offset.  No vector
+  // instruction per piece: the ablations (profiles/r03_ab_gemm_sp_ablation.log) showed that every VALU instruction between the
+  // MFMAs of a one-wave-per-SIMD stream costs ~10 cycles of matrix-pipe time -- the per-piece 64-bit pointer add of the
+  // global_load_lds form cost 14 %, the per-piece tap arithmetic of the conv A gather (11 VALU incl. a 64-bit multiply-add) 40 %.
+  // Lanes whose tap falls outside the image get an offset beyond the descriptor's range: the load returns zeros (the padding).
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, 0x80000000u, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;            // >= num_records for every scalar offset < 2^31 (no 32-bit wrap)
+  unsigned a_voff[PA], w_voff[PB];                 // per-lane byte offsets of this wave's pieces
+  int a_oy[PA], a_ox[PA];                          // conv: input row / column of filter tap (0, 0) of the lane's output pixel
+  unsigned a_img[PA];                              // conv: byte offset of the lane's image + its 16-byte slot
+  int is_it = 0, is_kt = 0;                        // output tile / K tile of the next tile to issue
+  int is_k0 = 0, is_c0 = 0, is_ky = 0, is_kx = 0;  // its K offset; conv: filter tap and first channel (k0 = tap * Cin + c0)
+  auto conv_tap_offsets = [&]() {                  // once per filter tap (every Cin / 32 K tiles), not per piece
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
+      const int iy = a_oy[j] + is_ky, ix = a_ox[j] + is_kx;
+      const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
+      const unsigned off = (((unsigned)(iy >> p.upsample) * (unsigned)p.Win + (unsigned)(ix >> p.upsample)) * (unsigned)p.Cin) * 2u + a_img[j];
+      a_voff[j] = ok ? off : OOB;
+    }
+  };
   auto set_sources = [&](int i) {
     int m0, n0;
     tile_origin(i, m0, n0);
@@ -171,41 +190,28 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
         a_oy[j] = oy * p.stride - p.pad;
         a_ox[j] = ox * p.stride - p.pad;
-        a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
+        a_img[j] = (unsigned)b * (unsigned)(p.Hin * p.Win) * (unsigned)p.Cin * 2u + lslot * 16;   // < 2^31 (sp_eligible)
       } else {
-        a_oy[j] = a_ox[j] = 0;
-        a_src[j] = p.A + (size_t)mm * p.lda + lslot * 8;
+        a_voff[j] = (unsigned)mm * (unsigned)p.lda * 2u + lslot * 16;                             // < 2^31 (sp_eligible)
       }
     }
+    if (CONV) conv_tap_offsets();
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       const int row = (wave * PB + j) * RPI + lrow;
-      w_src[j] = p.W + (size_t)(n0 + row) * p.K + (pslot ^ ((row >> 2) & 3)) * 8;      // N % BN == 0 (launcher)
+      w_voff[j] = (unsigned)(n0 + row) * (unsigned)p.K * 2u + (pslot ^ ((row >> 2) & 3)) * 16;    // N % BN == 0 (launcher)
     }
   };
-  const half_t* zero_src = g_zero_page + 0;
-  int is_it = 0, is_kt = 0;                       // output tile / K tile of the next tile to issue
-  int is_k0 = 0, is_c0 = 0, is_ky = 0, is_kx = 0;  // its K offset; conv: filter tap and first channel (k0 = tap * Cin + c0)
   set_sources(0);
   // one DMA instruction (piece) of the tile being issued: pieces 0 .. PA-1 are A rows, PA .. G-1 W rows
   auto issue_piece = [&](int stage, int pc) {
     if (pc < PA) {
-      char* dst = smem + stage * STAGE + (wave * PA + pc) * 1024;
-      if (CONV) {
-        const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
-        const int iy = a_oy[pc] + is_ky, ix = a_ox[pc] + is_kx;
-        const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
-        unsigned off = __umul24(__umul24((unsigned)(iy >> p.upsample), (unsigned)p.Win) + (unsigned)(ix >> p.upsample), (unsigned)p.Cin) + is_c0;
-        asm volatile("" : "+v"(off));
-        const half_t* src = a_src[pc] + off;
-        src = ok ? src : zero_src;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-      } else {
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[pc] + is_k0), (lptr_t)dst, 16, 0, 0);
-      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + stage * STAGE + (wave * PA + pc) * 1024), 16, a_voff[pc < PA ? pc : 0],
+                                               (CONV ? is_c0 : is_k0) * 2, 0, 0);
     } else {
       const int j = pc - PA;
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + is_k0), (lptr_t)(smem + stage * STAGE + OPA + (wave * PB + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem + stage * STAGE + OPA + (wave * PB + j) * 1024), 16, w_voff[pc < PA ? 0 : j],
+                                               is_k0 * 2, 0, 0);
     }
   };
   auto issue_advance = [&]() {
@@ -215,12 +221,14 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       if (is_c0 == p.Cin) {
         is_c0 = 0;
         if (++is_kx == 3) { is_kx = 0; ++is_ky; }
+        if (is_kt + 1 < nk) conv_tap_offsets();
       }
     }
     if (++is_kt == nk) {
       is_kt = 0;
       is_k0 = is_c0 = is_ky = is_kx = 0;
-      if (++is_it < ntile) set_sources(is_it);      // past the last tile: keep its sources (valid addresses, data never read)
+      if (++is_it < ntile) set_sources(is_it);      // past the last tile: keep its offsets (valid addresses, data never read)
+      else if (CONV) conv_tap_offsets();
     }
   };
 
@@ -267,20 +275,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         FBL[k < MT ? 0 : k - MT] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][k < MT ? 0 : k - MT]);  \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
-      if (!(SP_ABL & 2)) {                                                                                  \
-        if (SP_STAGGER) {                                                                                   \
-          /* wave w issues its j-th piece behind MFMA min(4 j + w, last): the four waves leave the barrier together and  */ \
-          /* run in step, so pieces issued at the same k queue up behind one another in the CU's one address path        */ \
-          if (k < 16 && (k & 3) == wave) {                                                                  \
-            issue_piece(DST, (PC0) + (k >> 2));                                                             \
-          } else if (MT * NT == 15 && k == 14 && wave == 3) {                                               \
-            issue_piece(DST, (PC0) + 3);                                                                    \
-          }                                                                                                 \
-          __builtin_amdgcn_sched_barrier(0);                                                                \
-        } else if (k % 3 == 1 && k < 12) {                                                                  \
-          issue_piece(DST, (PC0) + k / 3);                                                                  \
-          __builtin_amdgcn_sched_barrier(0);                                                                \
-        }                                                                                                   \
+      if (k % 3 == 1 && k < 12 && !(SP_ABL & 2)) {                                                          \
+        issue_piece(DST, (PC0) + k / 3);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
     }                                                                                                       \
   }
@@ -392,6 +389,10 @@ static bool sp_eligible(const GemmParams& p) {
   if (p.transpose_out || p.N % BN != 0 || p.K % 32 != 0 || p.K < 128 || p.N > 16384) return false;
   if (!GEGLU && p.act != ACT_NONE) return false;
   if (CONV && p.Cin % 32 != 0) return false;
+  // the DMA pieces address A and W through buffer descriptors with 32-bit byte offsets; offsets from 2^31 up mean "outside"
+  const unsigned long long a_bytes = CONV ? (unsigned long long)cdiv(p.M, p.Hout * p.Wout) * p.Hin * p.Win * p.Cin * 2
+                                          : ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2;
+  if (a_bytes >= (1ull << 31) || (unsigned long long)p.N * p.K * 2 >= (1ull << 31)) return false;
   if (!al16(p.C) || p.ldc % 8 != 0) return false;
   if (p.bias && !al16(p.bias)) return false;
   if (p.residual && (!al16(p.residual) || p.ldr % 8 != 0)) return false;

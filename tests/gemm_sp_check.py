@@ -1,5 +1,4 @@
-"""Parity + race screen of the persistent software-pipelined GEMM / conv flavours: gemm_sp.h (one wave per SIMD, MD_GEMM_SP=1) and
-gemm_tw.h (two free-running waves per SIMD, MD_GEMM_TW=1).  Run as a script with one of the two set (the dispatch
+"""Parity + race screen of the persistent one-wave-per-SIMD GEMM / conv flavour (gemm_sp.h).  Run as a script with MD_GEMM_SP=1 (the dispatch
 override is read once per process, so tests/test_gemm_sp_gpu.py spawns this file); every case goes through the C ABI and is
 compared with an fp32 PyTorch evaluation of the same fp16-rounded operands: |err| <= 1e-2 * maxabs(ref) + 1e-3.  Each case
 is also run three times and must be bit-identical run to run (an LDS ring race shows up as run-to-run differences)."""
@@ -13,7 +12,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mikudance_amd import ops, packing  # noqa: E402
 
-assert os.environ.get("MD_GEMM_SP") == "1" or os.environ.get("MD_GEMM_TW") == "1", "run with MD_GEMM_SP=1 or MD_GEMM_TW=1"
+assert os.environ.get("MD_GEMM_SP") == "1", "run with MD_GEMM_SP=1"
 dev = torch.device("cuda:0")
 
 

@@ -1,5 +1,5 @@
-"""GPU: the persistent software-pipelined GEMM / conv flavours (mikudance_amd/csrc/gemm_sp.h, gemm_tw.h) forced on for every eligible
-problem (MD_GEMM_SP=1 / MD_GEMM_TW=1 are read once per process, hence the subprocess): parity with fp32 PyTorch + run-to-run bit identity."""
+"""GPU: the persistent software-pipelined GEMM / conv flavours (mikudance_amd/csrc/gemm_sp.h) forced on for every eligible
+problem (MD_GEMM_SP=1 is read once per process, hence the subprocess): parity with fp32 PyTorch + run-to-run bit identity."""
 import os
 import subprocess
 import sys
@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("knob", ["MD_GEMM_SP", "MD_GEMM_TW"])
+@pytest.mark.parametrize("knob", ["MD_GEMM_SP"])
 def test_gemm_sp_parity_and_race_screen(knob):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, **{knob: "1"})
