@@ -112,6 +112,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
 
 template <bool CONV, bool GEGLU, int MT, int NT>
 __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub: it cannot lower the buffer-descriptor type used below
   constexpr int BK = 32;
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #undef SP_BODY
 #undef SP_READ
 #undef SP_HALF
+#endif
 }
 
 template <bool CONV, bool GEGLU>
