@@ -33,7 +33,7 @@
 // nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
 #ifndef SP_ABL
-#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
+#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait, 64 pieces read whole cache lines
 #endif
 
 // zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
@@ -201,6 +201,12 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     for (int j = 0; j < PB; ++j) {
       const int row = (wave * PB + j) * RPI + lrow;
       w_voff[j] = (unsigned)(n0 + row) * (unsigned)p.K * 2u + (pslot ^ ((row >> 2) & 3)) * 16;    // N % BN == 0 (launcher)
+    }
+    if (SP_ABL & 64) {   // diagnostic: every piece reads ONE contiguous KiB (8 whole 128-byte lines) instead of 16 rows x 64 bytes
+#pragma unroll
+      for (int j = 0; j < PA; ++j) a_voff[j] = (CONV ? 0u : (unsigned)min(m0 + (wave * PA + j) * RPI, p.M - 1) * (unsigned)p.lda * 2u) + lane * 16;
+#pragma unroll
+      for (int j = 0; j < PB; ++j) w_voff[j] = (unsigned)(n0 + (wave * PB + j) * RPI) * (unsigned)p.K * 2u + lane * 16;
     }
   };
   set_sources(0);
