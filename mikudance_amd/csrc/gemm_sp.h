@@ -1,5 +1,5 @@
 // gemm_sp_kernel: the "one wave per SIMD" flavour of the MFMA GEMM / implicit-GEMM 3x3 convolution (included by gemm.hip; same
-// operands, LDS image, swizzle and epilogue arithmetic as gemm_kernel / gemm_pp_kernel).
+// operands, swizzle idea and epilogue arithmetic as gemm_kernel / gemm_pp_kernel).
 //
 // Why a third structure.  gemm_pp_kernel keeps two waves per SIMD and alternates them between a fragment-load slot and an MFMA
 // slot with a workgroup barrier in between; its load slot (14 ds_read_b128 + 4-5 DMA pieces, ~830 cycles) is longer than its
@@ -10,30 +10,36 @@
 //     reads per 15 MFMAs; 192 divides every token count of the UNets and gives 294 912 x 320 six and 73 728 x 640 three exact
 //     rounds of 256 CUs); MT = NT = 4 -> 256 x 256 for GEGLU (h | g column pairing needs 64-column groups per wave);
 //   * the wave is software pipelined against ITSELF: the fragments of k-step u+1 are read into the other register set and
-//     the DMA pieces of the K tile 3-4 ahead are issued in the issue slots BETWEEN the MFMAs of step u (sched_group_barrier
-//     pins one ds_read_b128 behind each of the first MT + NT MFMAs and one DMA piece behind every third; giving each wave its own
-//     gaps for the pieces was measured 12-15 % slower: a scalar branch per gap costs more than the shared address path), so the matrix pipe
-//     never waits for a load slot;
-//   * K tiles of 32 in a 4-deep 32-KiB LDS ring filled by direct-to-LDS DMA (three tiles in flight, counted vmcnt), ONE
-//     s_barrier per K tile (per 30-32 MFMAs of every wave);
-//   * persistent: a workgroup walks over its output tiles and the ring keeps running across tile boundaries; the first k-step
-//     of an output tile accumulates onto the inline constant 0 (no accumulator clearing);
+//     the DMA pieces of the K tiles ahead are issued in the issue slots BETWEEN the MFMAs of step u (sched_barrier pins one
+//     ds_read_b128 behind each of the first MT + NT MFMAs and the step's DMA pieces behind evenly spaced MFMAs; giving each wave
+//     its own gaps for the pieces was measured 12-15 % slower: a scalar branch per gap costs more than the shared address path);
+//   * K tiles of 64: a tile row is ONE 128-byte cache line, so a DMA piece (64 lanes x 16 bytes) fetches 8 whole lines.  With
+//     K tiles of 32 (64-byte rows) every line was requested twice, a K tile apart, by 16-row pieces; the ablations
+//     (profiles/r03_ab_gemm_sp_dma_lines.log) price the DMA traffic of the main loop at 19-33 % of the time and show that pieces
+//     of whole lines give back 8-20 % of it (the vector address arithmetic of the first build, by contrast, cost nothing once
+//     the pieces went through buffer descriptors: what mattered was the number of L2 requests);
+//   * LDS ring of mixed depth, 152 / 160 KiB: THREE slots for the A tile (the streamed operand: an A piece is issued two K tiles
+//     = ~3 800 cycles before it is needed, enough for an HBM miss), TWO for the W tile (shared by every CU of the column panel,
+//     an L2 hit: issued 2-3 k-steps = >= 960 cycles ahead), counted vmcnt, ONE s_barrier per K tile (per 60-64 MFMAs of a wave);
+//   * persistent: a workgroup walks over its output tiles (grouped tile order, see tile_origin) and the ring keeps running across
+//     tile boundaries; the first k-step of an output tile accumulates onto the inline constant 0 (no accumulator clearing);
 //   * epilogue straight from the accumulators (operand roles swapped, acc = mfma(W, A): a lane owns ONE output row and four
 //     4-column pieces per 32-column sub-tile): v_permlane32_swap pairs the pieces of the two lane halves into 16-byte stores
 //     (and un-pairs 16-byte residual loads), no LDS staging, no barrier.
-// Synchronisation (tile g in ring slot g & 3; B_g = the barrier in the middle of tile g-1's body):
-//   body(g):  half 1: MFMA(g, k 0-15)  || read (g, k 16-31) -> F1 || DMA pieces 4-7 of tile g+3
-//             lgkmcnt(0), vmcnt(16): this wave's pieces of tile g+1 have landed; B_{g+1}
-//             half 2: MFMA(g, k 16-31) || read (g+1, k 0-15) -> F0 || DMA pieces 0-3 of tile g+4
-//   RAW: all pieces of tile g+1 are retired by their issuing waves before B_{g+1}; its first reader comes after B_{g+1}.
-//   WAR: slot g & 3 is refilled (tile g+4) after B_{g+1}; every read of tile g was retired (lgkmcnt(0)) before B_{g+1}.
-//   vmcnt counts stores too, but loads return in order: "at most 16 outstanding" implies that every load older than the 16
+// Synchronisation.  K tile t lives in A slot t % 3 and W slot t & 1; its four k-steps s = 0..3 use the fragment sets F0 / F1
+// alternately; the fragments of step (t, s+1) -- of (t+1, 0) for s = 3 -- are read during step (t, s).  Once per K tile, at the
+// START of step (t, 3):  lgkmcnt(0) (every read of tile t is retired), vmcnt(PA) (this wave's pieces of W(t+1) and A(t+1) have
+// landed; only its PA pieces of A(t+2) may still fly), s_barrier.
+//   RAW: the first reads of tile t+1 follow that barrier.
+//   WAR: behind the barrier the slots of tile t are refilled: the 16 pieces [W(t+2) | A(t+3)] of a wave go out in this order
+//        over the steps (t, 3), (t+1, 0), (t+1, 1), (t+1, 2) as 6 + 4 + 3 + 3, the W pieces first (they are needed one tile earlier).
+//   vmcnt counts stores too, but loads return in order: "at most PA outstanding" implies that every load older than the PA
 //   youngest loads has landed whatever the epilogue's stores do (at worst it waits for old stores as well).
-// DMA pieces are issued unconditionally (beyond the last K tile they re-read the last tile's first columns into a ring slot
-// nobody reads again), so every count is a compile-time constant; the kernel drains them before it ends.
+// DMA pieces are issued unconditionally (past the last K tile they re-read the last tile's first columns into ring slots nobody
+// reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
 #ifndef SP_ABL
-#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait, 64 pieces read whole cache lines
+#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
 #endif
 
 // zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
@@ -113,21 +119,20 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
 template <bool CONV, bool GEGLU, int MT, int NT>
 __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub: it cannot lower the buffer-descriptor type used below
-  constexpr int BK = 32;
+  constexpr int BK = 64;
   constexpr int BM = 64 * MT, BN = 64 * NT;
-  constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;
-  constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows, W rows
-  constexpr int G = PA + PB;
-  static_assert(G == 8, "the issue schedule below places 4 + 4 pieces per K tile");
+  constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;        // 128-byte rows, 8 rows per DMA piece
+  constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows (6 / 8), W rows (10 / 8)
+  static_assert(PA + PB == 16 && PB >= 6, "the issue schedule below places 6 + 4 + 3 + 3 pieces per K tile, W first");
   static_assert(!GEGLU || NT % 2 == 0, "GEGLU pairs 32-column sub-tiles (2q, 2q+1) of a wave");
-  constexpr int OPA = BM * ROWB, STAGE = (BM + BN) * ROWB;
+  constexpr int ASZ = BM * ROWB, WSZ = BN * ROWB, WBASE = 3 * ASZ;        // ring: A slots 0..2, then W slots 0..1
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int lrow = lane >> 2, pslot = lane & 3;
+  const int lrow = lane >> 3, pslot = lane & 7;
   const int nk = p.K / BK;
   const int nwg = p.tiles_total;
   const int ntile = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // output tiles of this workgroup
@@ -151,38 +156,35 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     n0 = tn * BN;
   };
 
-  // ------------------------------------------------------------------ issue side (runs 3-4 K tiles ahead of the compute side)
+  // ------------------------------------------------------------------ issue side: two streams, A three K tiles ahead, W two
   // A piece is ONE `buffer_load_dwordx4 ... offen lds`: buffer descriptor (SGPRs) + per-lane byte offset (one VGPR, constant per
-  // output tile -- per filter tap for a conv) + the K offset of the tile as the instruction's SCALAR offset.  No vector
-  // instruction per piece: the ablations (profiles/r03_ab_gemm_sp_ablation.log) showed that every VALU instruction between the
-  // MFMAs of a one-wave-per-SIMD stream costs ~10 cycles of matrix-pipe time -- the per-piece 64-bit pointer add of the
-  // global_load_lds form cost 14 %, the per-piece tap arithmetic of the conv A gather (11 VALU incl. a 64-bit multiply-add) 40 %.
-  // Lanes whose tap falls outside the image get an offset beyond the descriptor's range: the load returns zeros (the padding).
+  // output tile -- per filter tap for a conv) + the K offset of the tile as the instruction's SCALAR offset: no vector instruction
+  // per piece.  Lanes whose tap falls outside the image get an offset beyond the descriptor's range: the load returns zeros.
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, 0x80000000u, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;            // >= num_records for every scalar offset < 2^31 (no 32-bit wrap)
   unsigned a_voff[PA], w_voff[PB];                 // per-lane byte offsets of this wave's pieces
   int a_oy[PA], a_ox[PA];                          // conv: input row / column of filter tap (0, 0) of the lane's output pixel
   unsigned a_img[PA];                              // conv: byte offset of the lane's image + its 16-byte slot
-  int is_it = 0, is_kt = 0;                        // output tile / K tile of the next tile to issue
-  int is_k0 = 0, is_c0 = 0, is_ky = 0, is_kx = 0;  // its K offset; conv: filter tap and first channel (k0 = tap * Cin + c0)
-  auto conv_tap_offsets = [&]() {                  // once per filter tap (every Cin / 32 K tiles), not per piece
+  int ia_it = 0, ia_kt = 0, ia_k0 = 0, ia_c0 = 0, ia_ky = 0, ia_kx = 0, ia_slot = 0;   // A stream: next tile to issue
+  int iw_it = 0, iw_kt = 0, iw_k0 = 0, iw_slot = 0;                                   // W stream
+  auto conv_tap_offsets = [&]() {                  // once per filter tap (every Cin / 64 K tiles), not per piece
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
       const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
-      const int iy = a_oy[j] + is_ky, ix = a_ox[j] + is_kx;
+      const int iy = a_oy[j] + ia_ky, ix = a_ox[j] + ia_kx;
       const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
       const unsigned off = (((unsigned)(iy >> p.upsample) * (unsigned)p.Win + (unsigned)(ix >> p.upsample)) * (unsigned)p.Cin) * 2u + a_img[j];
       a_voff[j] = ok ? off : OOB;
     }
   };
-  auto set_sources = [&](int i) {
+  auto set_sources_a = [&](int i) {
     int m0, n0;
     tile_origin(i, m0, n0);
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
       const int row = (wave * PA + j) * RPI + lrow;
-      const int lslot = pslot ^ ((row >> 2) & 3);             // source-side swizzle (the DMA writes LDS lane-linearly)
+      const int lslot = pslot ^ ((row >> 1) & 7);             // source-side swizzle (the DMA writes LDS lane-linearly)
       const int m = m0 + row;
       const int mm = m < p.M ? m : p.M - 1;
       if (CONV) {
@@ -197,78 +199,85 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       }
     }
     if (CONV) conv_tap_offsets();
+  };
+  auto set_sources_w = [&](int i) {
+    int m0, n0;
+    tile_origin(i, m0, n0);
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       const int row = (wave * PB + j) * RPI + lrow;
-      w_voff[j] = (unsigned)(n0 + row) * (unsigned)p.K * 2u + (pslot ^ ((row >> 2) & 3)) * 16;    // N % BN == 0 (launcher)
-    }
-    if (SP_ABL & 64) {   // diagnostic: every piece reads ONE contiguous KiB (8 whole 128-byte lines) instead of 16 rows x 64 bytes
-#pragma unroll
-      for (int j = 0; j < PA; ++j) a_voff[j] = (CONV ? 0u : (unsigned)min(m0 + (wave * PA + j) * RPI, p.M - 1) * (unsigned)p.lda * 2u) + lane * 16;
-#pragma unroll
-      for (int j = 0; j < PB; ++j) w_voff[j] = (unsigned)(n0 + (wave * PB + j) * RPI) * (unsigned)p.K * 2u + lane * 16;
+      w_voff[j] = (unsigned)(n0 + row) * (unsigned)p.K * 2u + (pslot ^ ((row >> 1) & 7)) * 16;    // N % BN == 0 (launcher)
     }
   };
-  set_sources(0);
-  // one DMA instruction (piece) of the tile being issued: pieces 0 .. PA-1 are A rows, PA .. G-1 W rows
-  auto issue_piece = [&](int stage, int pc) {
-    if (pc < PA) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + stage * STAGE + (wave * PA + pc) * 1024), 16, a_voff[pc < PA ? pc : 0],
-                                               (CONV ? is_c0 : is_k0) * 2, 0, 0);
-    } else {
-      const int j = pc - PA;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem + stage * STAGE + OPA + (wave * PB + j) * 1024), 16, w_voff[pc < PA ? 0 : j],
-                                               is_k0 * 2, 0, 0);
-    }
+  set_sources_a(0);
+  set_sources_w(0);
+  auto issue_a = [&](int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + ia_slot * ASZ + (wave * PA + j) * 1024), 16, a_voff[j], (CONV ? ia_c0 : ia_k0) * 2, 0, 0);
   };
-  auto issue_advance = [&]() {
-    is_k0 += BK;
+  auto issue_w = [&](int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem + WBASE + iw_slot * WSZ + (wave * PB + j) * 1024), 16, w_voff[j], iw_k0 * 2, 0, 0);
+  };
+  auto advance_a = [&]() {
+    ia_k0 += BK;
+    if (++ia_slot == 3) ia_slot = 0;
     if (CONV) {
-      is_c0 += BK;
-      if (is_c0 == p.Cin) {
-        is_c0 = 0;
-        if (++is_kx == 3) { is_kx = 0; ++is_ky; }
-        if (is_kt + 1 < nk) conv_tap_offsets();
+      ia_c0 += BK;
+      if (ia_c0 == p.Cin) {
+        ia_c0 = 0;
+        if (++ia_kx == 3) { ia_kx = 0; ++ia_ky; }
+        if (ia_kt + 1 < nk) conv_tap_offsets();
       }
     }
-    if (++is_kt == nk) {
-      is_kt = 0;
-      is_k0 = is_c0 = is_ky = is_kx = 0;
-      if (++is_it < ntile) set_sources(is_it);      // past the last tile: keep its offsets (valid addresses, data never read)
+    if (++ia_kt == nk) {
+      ia_kt = 0;
+      ia_k0 = ia_c0 = ia_ky = ia_kx = 0;
+      if (++ia_it < ntile) set_sources_a(ia_it);    // past the last tile: keep its offsets (valid addresses, data never read)
       else if (CONV) conv_tap_offsets();
+    }
+  };
+  auto advance_w = [&]() {
+    iw_k0 += BK;
+    iw_slot ^= 1;
+    if (++iw_kt == nk) {
+      iw_kt = 0;
+      iw_k0 = 0;
+      if (++iw_it < ntile) set_sources_w(iw_it);
+    }
+  };
+  // piece q = 0..15 of the list [W pieces 0..PB-1 | A pieces 0..PA-1]; each stream moves on behind its last piece
+  auto issue_q = [&](int q) {
+    if (q < PB) {
+      issue_w(q < PB ? q : 0);
+      if (q == PB - 1) advance_w();
+    } else {
+      issue_a(q < PB ? 0 : q - PB);
+      if (q == PB + PA - 1) advance_a();
     }
   };
 
   // ------------------------------------------------------------------ compute side
   const int frow = lane & 31, fhi = lane >> 5;
-  int a_rd[2][MT], b_rd[2][NT];                    // per-lane LDS byte offsets of the fragment reads of k-step s = 0, 1
+  int a_rd[4][MT], b_rd[4][NT];                    // per-lane LDS byte offsets of the fragment reads of k-step s = 0..3 (within a slot)
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < 4; ++s) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int ra = wm * (32 * MT) + i * 32 + frow;
-      a_rd[s][i] = ra * ROWB + (((s * 2 + fhi) ^ ((ra >> 2) & 3)) << 4);
+      a_rd[s][i] = ra * ROWB + (((s * 2 + fhi) ^ ((ra >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int rb = wn * (32 * NT) + j * 32 + frow;
-      b_rd[s][j] = OPA + rb * ROWB + (((s * 2 + fhi) ^ ((rb >> 2) & 3)) << 4);
+      b_rd[s][j] = WBASE + rb * ROWB + (((s * 2 + fhi) ^ ((rb >> 1) & 7)) << 4);
     }
   }
   floatx16 acc[MT][NT];
   half8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
 
-#define SP_READ(FA, FB, SB, S)                                                                              \
-  {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *reinterpret_cast<const half8_t*>((SB) + a_rd[S][i]); \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) FB[j] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][j]); \
-  }
-  // One k-step (half a K tile), issue order pinned by hand (sched_barrier(0) lets nothing cross): MFMA k of the current
-  // fragments (FAU, FBU), then -- behind each of the first MT + NT MFMAs -- ONE ds_read_b128 of the next k-step's fragments (FAL,
-  // FBL from ring stage SB, k-step S), and behind MFMAs 1, 4, 7, 10 ONE DMA piece (PC0 ..) into ring stage DST.  All four waves
-  // of the workgroup leave the barrier together, so a burst of 8 reads + 4 pieces per wave would queue up in front of the
-  // LDS / texture path and stall the in-order wave's next MFMA; spread out, every gap carries at most three instructions.
-#define SP_HALF(FAU, FBU, FAL, FBL, SB, S, ZERO, DST, PC0)                                                  \
+  // One k-step, issue order pinned by hand (sched_barrier(0) lets nothing cross): MFMA k of the current fragments (FAU, FBU),
+  // then -- behind each of the first MT + NT MFMAs -- ONE ds_read_b128 of the next k-step's fragments (FAL, FBL: A slot offset
+  // SA, W slot offset SW, k-step S), and NP DMA pieces Q0 .. Q0+NP-1 of the list, evenly spaced.
+#define SP_STEP(FAU, FBU, FAL, FBL, SA, SW, S, ZERO, Q0, NP)                                                \
   {                                                                                                         \
     _Pragma("unroll") for (int k = 0; k < MT * NT; ++k) {                                                   \
       const int i = k / NT, j = k % NT;                                                                     \
@@ -276,31 +285,42 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       if (SP_ABL & 4) {                                                                                     \
       } else if (k < MT) {                                                                                  \
-        FAL[k < MT ? k : 0] = *reinterpret_cast<const half8_t*>((SB) + a_rd[S][k < MT ? k : 0]);            \
+        FAL[k < MT ? k : 0] = *reinterpret_cast<const half8_t*>(smem + (SA) + a_rd[S][k < MT ? k : 0]);     \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       } else if (k < MT + NT) {                                                                             \
-        FBL[k < MT ? 0 : k - MT] = *reinterpret_cast<const half8_t*>((SB) + b_rd[S][k < MT ? 0 : k - MT]);  \
+        FBL[k < MT ? 0 : k - MT] = *reinterpret_cast<const half8_t*>(smem + (SW) + b_rd[S][k < MT ? 0 : k - MT]); \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
-      if (k % 3 == 1 && k < 12 && !(SP_ABL & 2)) {                                                          \
-        issue_piece(DST, (PC0) + k / 3);                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
+      if (!(SP_ABL & 2)) {                                                                                  \
+        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? 3 : 4);                                         \
+        if (k % STRIDE == 1 && k / STRIDE < (NP)) {                                                         \
+          issue_q((Q0) + k / STRIDE);                                                                       \
+          __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
   }
 
-  // ------------------------------------------------------------------ prologue: tiles 0, 1, 2 and the first half of tile 3
-#pragma unroll 1
-  for (int s = 0; s < 3; ++s) {
+  // ------------------------------------------------------------------ prologue
+  // W(0), A(0), A(1), then the first 6 pieces of the list [W(1) | A(2)] (the share of a step 3); the steps 0..2 of tile 0 issue
+  // the other 10 like every later tile
 #pragma unroll
-    for (int pc = 0; pc < G; ++pc) issue_piece(s, pc);
-    issue_advance();
+  for (int j = 0; j < PB; ++j) issue_w(j);
+  advance_w();
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int j = 0; j < PA; ++j) issue_a(j);
+    advance_a();
   }
 #pragma unroll
-  for (int pc = 0; pc < 4; ++pc) issue_piece(3, pc);
-  wait_vmcnt<2 * G + 4>();                                           // this wave's pieces of tile 0
+  for (int q = 0; q < 6; ++q) issue_q(q);
+  wait_vmcnt<PA + 6>();                                              // this wave's pieces of W(0) and A(0)
   __builtin_amdgcn_s_barrier();
-  SP_READ(fa0, fb0, smem, 0)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) fa0[i] = *reinterpret_cast<const half8_t*>(smem + a_rd[0][i]);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb0[j] = *reinterpret_cast<const half8_t*>(smem + b_rd[0][j]);
 
   // One K tile of the main loop.  ZERO: first K tile of an output tile (its first k-step accumulates onto the inline constant 0).
   // The first K tile is PEELED out of the K loop instead of being selected inside it: a select would merge two definitions of
@@ -308,20 +328,19 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   // scratch on every iteration.
 #define SP_BODY(ZERO)                                                                                       \
   {                                                                                                         \
-    const char* sb = smem + (g & 3) * STAGE;                                                                \
-    const char* sbn = smem + ((g + 1) & 3) * STAGE;                                                         \
-    /* half 1: MFMA (g, k 0-15) || read (g, k 16-31) -> F1 || pieces 4-7 of tile g+3 */                     \
-    SP_HALF(fa0, fb0, fa1, fb1, sb, 1, ZERO, (g + 3) & 3, 4)                                                \
-    issue_advance();                                                                                        \
+    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, 6, 4)                                                      \
+    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, 10, 3)                                                    \
+    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, 13, 3)                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    if (!(SP_ABL & 8)) wait_vmcnt<2 * G>(); /* this wave's pieces of tile g+1 (tiles g+2, g+3 may fly) */   \
-    if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier(); /* B_{g+1} */                                          \
-    /* half 2: MFMA (g, k 16-31) || read (g+1, k 0-15) -> F0 || pieces 0-3 of tile g+4 -> the slot tile g has left */ \
-    SP_HALF(fa1, fb1, fa0, fb0, sbn, 0, false, g & 3, 0)                                                    \
-    ++g;                                                                                                    \
+    if (!(SP_ABL & 8)) wait_vmcnt<PA>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
+    if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier();                                                        \
+    ca += ASZ;                                                                                              \
+    if (ca == 3 * ASZ) ca = 0;                                                                              \
+    cw ^= WSZ;                                                                                              \
+    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 0, false, 0, 6)                                                     \
   }
 
-  int g = 0;
+  int ca = 0, cw = 0;                               // A / W slot offsets of the tile being multiplied
 #pragma unroll 1
   for (int ct = 0; ct < ntile; ++ct) {
     SP_BODY(true)
@@ -385,8 +404,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   }
   wait_vmcnt<0>();                                                   // the DMA pieces issued past the last tile
 #undef SP_BODY
-#undef SP_READ
-#undef SP_HALF
+#undef SP_STEP
 #endif
 }
 
@@ -394,9 +412,9 @@ template <bool CONV, bool GEGLU>
 static bool sp_eligible(const GemmParams& p) {
   constexpr int BN = GEGLU ? 256 : 320;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (p.transpose_out || p.N % BN != 0 || p.K % 32 != 0 || p.K < 128 || p.N > 16384) return false;
+  if (p.transpose_out || p.N % BN != 0 || p.K % 64 != 0 || p.K < 128 || p.N > 16384) return false;
   if (!GEGLU && p.act != ACT_NONE) return false;
-  if (CONV && p.Cin % 32 != 0) return false;
+  if (CONV && p.Cin % 64 != 0) return false;
   // the DMA pieces address A and W through buffer descriptors with 32-bit byte offsets; offsets from 2^31 up mean "outside"
   const unsigned long long a_bytes = CONV ? (unsigned long long)cdiv(p.M, p.Hout * p.Wout) * p.Hin * p.Win * p.Cin * 2
                                           : ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2;
@@ -412,7 +430,7 @@ template <bool CONV, bool GEGLU>
 static void launch_sp(GemmParams& p, hipStream_t stream) {
   constexpr int MT = GEGLU ? 4 : 3, NT = GEGLU ? 4 : 5;
   constexpr int BM = 64 * MT, BN = 64 * NT;
-  constexpr size_t smem = (size_t)4 * (BM + BN) * 64;
+  constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128;          // A ring of three, W ring of two 64-deep K tiles
   md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
   constexpr int group_m = 8;       // row-major order (1) measured 3-38 % slower on the wide-N shapes (profiles/r03_ab_gemm_sp.log)
   p.tiles_n = p.N / BN;
