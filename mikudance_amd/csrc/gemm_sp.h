@@ -379,8 +379,12 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
             for (int gi = 0; gi < 4; ++gi) {
               half4_t o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                o[e] = (half_t)((sp_acc(acc[i][2 * q], 4 * gi + e) + (float)bh[gi][e]) * gelu_fast(sp_acc(acc[i][2 * q + 1], 4 * gi + e) + (float)bg[gi][e]));
+              for (int e = 0; e < 4; e += 2) {
+                const float2_t gl = gelu_fast2(float2_t{sp_acc(acc[i][2 * q + 1], 4 * gi + e) + (float)bg[gi][e],
+                                                        sp_acc(acc[i][2 * q + 1], 4 * gi + e + 1) + (float)bg[gi][e + 1]});
+                o[e] = (half_t)((sp_acc(acc[i][2 * q], 4 * gi + e) + (float)bh[gi][e]) * gl.x);
+                o[e + 1] = (half_t)((sp_acc(acc[i][2 * q], 4 * gi + e + 1) + (float)bh[gi][e + 1]) * gl.y);
+              }
               __builtin_memcpy(w[gi], &o, 8);
             }
 #pragma unroll
