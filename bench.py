@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the AutoencoderKL timing behind the extra keys vae_ms_per_clip / e2e_frames_per_s")
     ap.add_argument("--no-reuse", action="store_true", help="literal reference algorithm: reference UNet at every step on 2f frames")
     ap.add_argument("--small", action="store_true", help="reduced-width UNets (debug only; NOT the benchmark)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
@@ -196,6 +197,14 @@ def main():
                 fh.write(f"{v['ms'] / inst_steps:10.3f} ms/clip  {v['count'] // inst_steps:6d} launches  "
                          f"{(v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else 0:8.1f} TF  "
                          f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}\n")
+    if world == 1 and not args.small and not args.no_vae:
+        # SURVEY 8d reports the VAE beside the headline, never inside it: 3F + 2 encodes and F decodes per clip (the calls of
+        # src/pipelines/pipeline_mikudance.py:456-549 and :115-130), batches of 8 images as the product pipeline issues them
+        del ref, den, pipe
+        torch.cuda.empty_cache()
+        vae_ms = vae_ms_per_clip(dev, args.size, args.frames)
+        line["vae_ms_per_clip"] = vae_ms
+        line["e2e_frames_per_s"] = args.frames / (elapsed / args.steps + vae_ms * 1e-3)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ref_sd, den_sd, args, ctx)
     print(json.dumps(line))
@@ -222,6 +231,32 @@ def full_guidance(ref_latents, frames, h, w):
     return out
 
 
+def vae_ms_per_clip(dev, size, frames, batch=8):
+    """AutoencoderKL (sd-vae-ft-mse geometry, seeded random weights) at the benchmark size: F decodes + 3F + 2 encodes, timed once
+    after a warm-up pass.  Not part of `value` (the metric is the denoising loop)."""
+    from mikudance_amd import AutoencoderKL
+    from mikudance_amd.synth import synth_state_dict
+    vae = AutoencoderKL()
+    vae.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed=77), strict=True)
+    vae = vae.half().to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(7)
+    lat = torch.randn(frames, 4, size // 8, size // 8, device=dev, generator=g).half()
+    imgs = (torch.rand(3 * frames + 2, 3, size, size, device=dev, generator=g) * 2 - 1).half()
+
+    def once():
+        for i in range(0, frames, batch):
+            vae.decode(lat[i:i + batch]).sample
+        for i in range(0, imgs.shape[0], batch):
+            vae.encode(imgs[i:i + batch]).latent_dist.mean
+    with torch.no_grad():
+        once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        once()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
 def cpu_baseline(ref_sd, den_sd, args, ctx):
     """The CPU oracle (a port of the reference's PyTorch path: the same ATen ops, fp32) on this host's cores, on a bounded
     sample, after one untimed warm-up pass (thread pool, allocator, oneDNN primitive caches):
@@ -229,7 +264,9 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
       (2) ONE DDIM step at the benchmark resolution on f = 2 frames (reference_unet + denoising_unet on the [uncond | cond]
           pair with temporal attention over the 2 frames) -- `value` = 2 frames / (ddim_steps x that time), i.e. the step
           time extrapolated linearly over the steps; a full 16-frame clip is ~2 PFLOP = hours of CPU.
-    `cores` = torch's intra-op threads actually used; the physical core count of the host is reported beside it."""
+    configs[0] runs on the best intra-op thread count of a sweep over 8 / 16 / 32 / 64 / all threads on one of its steps
+    (`config1_cores`, `thread_sweep_s_per_step`); the 768x768 step behind `value` uses all threads (`cores`); the physical core
+    count of the host is reported beside them."""
     from oracle import cpu_ref as O                                     # cpu_baseline leg only
     from mikudance_amd.synth import synth_inputs
     try:
@@ -237,25 +274,40 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
         physical = psutil.cpu_count(logical=False)
     except Exception:
         physical = None
-    threads = torch.get_num_threads()
     full_ctx = (257, 768) if not args.small else ctx
+    avail = torch.get_num_threads()
+    sweep = {}
     with torch.no_grad():
         lat1, rl1, emb1 = synth_inputs(4, 32, 32, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100)
         O.denoise_loop(ref_sd, den_sd, lat1, rl1, emb1, 1, guidance_scale=args.guidance)          # warm-up (untimed)
+        # intra-op thread sweep on ONE DDIM step of configs[0]: ATen's small convs / GEMMs at this size stop scaling long before
+        # 128 threads (the survey measured 8.5 s per step on 8 cores where 128 threads take ~18 s); the best count is used below
+        for n in sorted({n for n in (8, 16, 32, 64, avail) if n <= avail}):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            O.denoise_loop(ref_sd, den_sd, lat1, rl1, emb1, 1, guidance_scale=args.guidance)
+            sweep[n] = time.perf_counter() - t0
+        threads = min(sweep, key=sweep.get)
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
         O.denoise_loop(ref_sd, den_sd, lat1, rl1, emb1, 4, guidance_scale=args.guidance)
         dt1 = time.perf_counter() - t0
+        # the 768x768 step is made of large convolutions / GEMMs that do use every core: all threads (the sweep above is about
+        # the small operators of configs[0])
+        torch.set_num_threads(avail)
         h = w = args.size // 8
         f = 2
         lat, rl, emb = synth_inputs(f, h, w, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100)
         t0 = time.perf_counter()
         O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
         dt2 = time.perf_counter() - t0
-    return {"value": f / (dt2 * args.ddim_steps), "unit": "frames/s", "cores": threads, "physical_cores": physical, "kind": "port",
+    return {"value": f / (dt2 * args.ddim_steps), "unit": "frames/s", "cores": avail, "physical_cores": physical, "kind": "port",
+            "config1_cores": threads, "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
             "config1_full_s": dt1, "config1_frames_per_s": 4.0 / dt1,
-            "sample": f"after one warm-up pass: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) = {dt1:.1f} s; "
+            "sample": f"after one warm-up pass: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) on {threads} intra-op threads "
+                      f"(best of the sweep) = {dt1:.1f} s; "
                       f"(2) 1 DDIM step of {f} frames at {args.size}x{args.size} (reference_unet + denoising_unet, CFG pair, fp32, full-width "
-                      f"random-init weights) = {dt2:.1f} s; value = {f} frames / ({args.ddim_steps} steps x {dt2:.1f} s)"}
+                      f"random-init weights) on {avail} threads = {dt2:.1f} s; value = {f} frames / ({args.ddim_steps} steps x {dt2:.1f} s)"}
 
 
 if __name__ == "__main__":

@@ -506,7 +506,6 @@ static int md_device_cus() {
   return n;
 }
 
-#include "gemm_pp.h"
 #include "gemm_ws.h"
 #include "gemm_sp.h"
 
@@ -574,9 +573,9 @@ static bool ws_eligible(const GemmParams& p) {
 
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
-  // Dispatch table, from same-box A/B runs on MI355X (profiles/r0*_ab_*.log).  Two knobs survive, both used by
-  // the parity tests: MD_GEMM_PP / MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).
-  static const int pp = env_int("MD_GEMM_PP", 2);
+  // Dispatch table, from same-box A/B runs on MI355X (profiles/r0*_ab_*.log).  One knob survives, used by the
+  // parity tests: MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).  (The two-waves-per-SIMD ping-pong
+  // kernels of rounds 1-2, gemm_pp.h, lost every shape they used to win to gemm_sp_kernel and were removed in round 3.)
   static const int sp = env_int("MD_GEMM_SP", 2);
   if (sp == 1 && sp_eligible<CONV, GEGLU>(p)) {
     launch_sp<CONV, GEGLU>(p, stream);
@@ -596,7 +595,7 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
       return;
     }
   }
-  // 2. one-wave-per-SIMD flavour (gemm_sp.h): every 3x3 conv with at least 192 tiles of 192 x 320 (+3..28 % over the ping-pong /
+  // 2. one-wave-per-SIMD flavour (gemm_sp.h): every 3x3 conv with at least 192 tiles of 192 x 320 (+3..37 % over the round-2 ping-pong /
   //    128 x 128 kernels; the 12 x 12 level's 96 tiles run 17 % slower), GEGLU GEMMs with K >= 640 (+4..16 %), plain GEMMs with
   //    at least 512 tiles (+4..20 %) or at least 256 tiles and K >= 2560 (+5..14 %); M = 18 432 x N = 1280 x K = 1280 (384 tiles =
   //    1.5 rounds of 256 CUs) stays on the 128 x 128 kernel (-3..-7 %)
@@ -608,25 +607,7 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
       return;
     }
   }
-  // 3. ping-pong flavour (gemm_pp.h): one 512-thread workgroup per CU, so it needs (nearly) full rounds of 256 tiles and a K
-  //    loop long enough to amortise its prologue / epilogue, which no other workgroup covers
-  if (pp > 0 && pp_eligible<CONV, GEGLU>(p)) {
-    const long tiles = (long)cdiv(p.M, 256) * (p.N / (GEGLU ? 256 : 320));
-    const long rounds = (tiles + 255) / 256;
-    const long fill = tiles * 100 / (rounds * 256);               // % of the CU-rounds that carry a tile
-    if constexpr (GEGLU) {
-      // persistent flavour (gemm_ppg_kernel): the DMA ring runs across output tiles, so short K loops pay no prologue
-      if (pp == 1 || (tiles >= 256 && p.K >= 640)) {
-        launch_ppg(p, stream);
-        return;
-      }
-    }
-    if (pp == 1 || (fill >= 88 && p.K >= 640) || (fill >= 75 && p.K >= 5760)) {
-      launch_pp<CONV, GEGLU>(p, stream);
-      return;
-    }
-  }
-  // 4. the occupancy flavours of gemm_kernel
+  // 3. the occupancy flavours of gemm_kernel
   if constexpr (!GEGLU) {
     if (p.N <= 64) {                                              // 64-column tiles: conv_out (N = 4), MAN's first conv
       if (CONV) launch_variant<CONV, false, 1, 64, 2>(p, stream);

@@ -1,7 +1,8 @@
 // gemm_sp_kernel: the "one wave per SIMD" flavour of the MFMA GEMM / implicit-GEMM 3x3 convolution (included by gemm.hip; same
-// operands, swizzle idea and epilogue arithmetic as gemm_kernel / gemm_pp_kernel).
+// operands, swizzle idea and epilogue arithmetic as gemm_kernel).
 //
-// Why a third structure.  gemm_pp_kernel keeps two waves per SIMD and alternates them between a fragment-load slot and an MFMA
+// Why this structure.  The "ping-pong" kernel of rounds 1-2 (gemm_pp.h, removed in round 3 after this one beat it on every shape)
+// kept two waves per SIMD and alternated them between a fragment-load slot and an MFMA
 // slot with a workgroup barrier in between; its load slot (14 ds_read_b128 + 4-5 DMA pieces, ~830 cycles) is longer than its
 // MFMA slot (20 MFMAs, ~700 cycles), so the matrix pipe of a SIMD is busy ~64 % of the time at best, and with 256 registers
 // per wave the wave tile is 64 x 160 (0.7 fragment reads per MFMA).  Here a 256-thread workgroup owns the CU with ONE wave per

@@ -11,6 +11,14 @@
 #ifndef GN_THREADS
 #define GN_THREADS 512
 #endif
+#ifndef MD_NT_STORES
+#define MD_NT_STORES 0   // A/B build: 1 = non-temporal stores for the streamed outputs of GroupNorm-apply and LayerNorm
+#endif
+template <typename T>
+__device__ __forceinline__ void norm_store(T* p, const T& v) {
+  if (MD_NT_STORES) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 #ifndef GN_SLAB
 #define GN_SLAB 32      // rows per row-lane and slab (same-box sweep on MI355X: 8: -35 %, 16: baseline, 24-32: +9 ... +20 %, 64: -8 %)
 #endif
@@ -122,7 +130,7 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
       if (silu) f = silu_f(f);
       o[e] = (half_t)f;
     }
-    *reinterpret_cast<half8_t*>(y + base + (size_t)p * C) = o;
+    norm_store(reinterpret_cast<half8_t*>(y + base + (size_t)p * C), o);
   }
 }
 
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[r][k][e] - mu[r]) * rs * (float)g[k][e] + (float)bt[k][e]);
-        *reinterpret_cast<half8_t*>(y + (size_t)row * C + c * 8) = o;
+        norm_store(reinterpret_cast<half8_t*>(y + (size_t)row * C + c * 8), o);
         if (y2) {
           half8_t o2 = o;
           if (addp) {
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 #pragma unroll
             for (int e = 0; e < 8; ++e) o2[e] = (half_t)((float)o[e] + (float)a[e]);  // fp16 n + fp16 bank, one rounding
           }
-          *reinterpret_cast<half8_t*>(y2 + (size_t)row * C + c * 8) = o2;
+          norm_store(reinterpret_cast<half8_t*>(y2 + (size_t)row * C + c * 8), o2);
         }
       }
     }

@@ -213,7 +213,7 @@ def g8_fullwidth():
 def g9_fullsize():
     """FULL-WIDTH UNet pair at BASELINE configs[1] spatial size (96x96 latents = 768x768 pixels, Lq = Lk = 9216 at d = 40),
     f = 2 frames, CFG: one evaluation with the reference's literal call pattern (pipeline_mikudance.py:626-660).  This is
-    the size at which the GPU build's automatic dispatch picks the ping-pong conv/GEMM kernels and the folded d=40
+    the size at which the GPU build's automatic dispatch picks the big-tile conv/GEMM kernels and the folded d=40
     attention, so the HIP path is pinned to the reference's own modules at its benchmark shapes.  Only `pred` is stored."""
     from src.models.mutual_mix_attention import ReferenceAttentionControl
     ref, den, ref_sd, den_sd = build_unets(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)

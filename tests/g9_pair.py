@@ -1,7 +1,7 @@
 """One UNet-pair evaluation at the G9 shape (full-width UNets, 96x96 latents, f = 2, CFG, literal reference call pattern,
 weights / inputs regenerated from the seeds in tests/golden/g9_meta.json) through the product path; writes the prediction
 to argv[1].  tests/test_unets_gpu.py runs it in a subprocess under kernel-dispatch settings that are read once per process
-(MD_GEMM_PP=1: the ping-pong conv / GEMM / persistent GEGLU kernels on every eligible problem) and compares with the golden
+(MD_GEMM_SP=1: the persistent one-wave-per-SIMD conv / GEMM / GEGLU kernels of gemm_sp.h on every eligible problem) and compares with the golden
 produced by the reference's own modules."""
 import json
 import os

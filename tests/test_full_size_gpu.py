@@ -1,7 +1,7 @@
-"""GPU, BASELINE.json configs[1] size: the kernels that are only selected at full size (the ping-pong GEMM / conv flavour
-needs >= 0.88 full rounds of 256 tiles) against the small-tile kernels that the oracle parity tests cover, in situ: one
-whole DDIM step (reference UNet write pass, denoising UNet read pass with CFG, DDIM) with MD_GEMM_PP=0 and with the
-automatic selection must agree to fp16 accumulation-order noise: relative L2 <= 2e-3, cosine >= 0.99999."""
+"""GPU, BASELINE.json configs[1] size: the kernels that are only selected at full size (the one-wave-per-SIMD GEMM / conv
+flavour of gemm_sp.h needs >= 192 conv tiles / >= 256..512 GEMM tiles) against the small-tile kernels that the oracle parity tests
+cover, in situ: one whole DDIM step (reference UNet write pass, denoising UNet read pass with CFG, DDIM) with MD_GEMM_SP=0 and
+with the automatic selection must agree to fp16 accumulation-order noise: relative L2 <= 2e-3, cosine >= 0.99999."""
 import os
 import subprocess
 import sys
@@ -21,10 +21,10 @@ def _run(env_extra, path):
     return torch.load(path)
 
 
-def test_full_size_step_pingpong_vs_small_tile_kernels():
+def test_full_size_step_big_tile_vs_small_tile_kernels():
     with tempfile.TemporaryDirectory() as d:
-        a = _run({"MD_GEMM_PP": "0"}, os.path.join(d, "a.pt"))
-        b = _run({"MD_GEMM_PP": "2"}, os.path.join(d, "b.pt"))
+        a = _run({"MD_GEMM_SP": "0"}, os.path.join(d, "a.pt"))
+        b = _run({"MD_GEMM_SP": "2"}, os.path.join(d, "b.pt"))
     assert a.shape == b.shape == (1, 4, 16, 96, 96)
     rel = float((a - b).norm() / a.norm())
     cos = float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))

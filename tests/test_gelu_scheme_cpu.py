@@ -1,4 +1,4 @@
-"""The GEGLU epilogues (mikudance_amd/csrc/gemm.hip gelu_fast2, used by gemm_kernel / gemm_pp / gemm_ppg / gemm_sp / wsgemm) evaluate
+"""The GEGLU epilogues (mikudance_amd/csrc/gemm.hip gelu_fast2, used by gemm_kernel / gemm_sp / wsgemm) evaluate
 the exact-erf GELU of the reference (diffusers GEGLU -> F.gelu(approximate='none'), src/models/attention.py:152-157) as
     gelu(x) = max(x, 0) - |x| / p(|x|)^16,   p = sum c_k |x|^k,  c_k = a_k 2^(1/16) 2^(-k/2),
 a_k the coefficients of Abramowitz-Stegun 7.1.28 (erf(z) = 1 - 1 / (1 + a1 z + .. + a6 z^6)^16, |error| <= 3e-7): six FMAs, four

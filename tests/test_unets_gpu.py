@@ -290,10 +290,10 @@ def test_g8_full_width_unets_vs_reference_golden(full, golden_dir):
 def test_g9_full_size_unets_vs_reference_golden(full, golden_dir):
     """The benchmark's OWN spatial size: full-width UNets at 96 x 96 latents (768 x 768 pixels; Lq = Lk = 9216 at d = 40,
     2304 at d = 80, 576 at d = 160), f = 2, CFG, against the reference's own modules (g9 <- oracle/gen_golden.py g9).  With
-    the automatic dispatch this runs the kernels that only exist at this size -- the ping-pong conv / GEMM, the persistent
-    GEGLU GEMM, the FOLD attention over 144 key tiles -- so they are pinned to the reference, not to each other."""
+    the automatic dispatch this runs the kernels that only exist at this size -- the 192 x 320 conv tiles of gemm_sp.h, the
+    W-stationary streaming GEMMs, the FOLD attention over 144 key tiles -- so they are pinned to the reference, not to each other."""
     from mikudance_amd.synth import synth_inputs
-    assert os.environ.get("MD_GEMM_PP", "2") == "2"                    # automatic kernel selection
+    assert os.environ.get("MD_GEMM_SP", "2") == "2"                    # automatic kernel selection
     meta = json.load(open(os.path.join(golden_dir, "g9_meta.json")))
     gold = load_file(os.path.join(golden_dir, "g9_fullsize_pred.safetensors"))["g9.pred"].float()
     ref, den, _, _ = full
@@ -304,15 +304,16 @@ def test_g9_full_size_unets_vs_reference_golden(full, golden_dir):
     assert r < 3e-2 and c > 0.999, (r, c)
 
 
-def test_g9_full_size_pingpong_kernels_vs_reference_golden(golden_dir, tmp_path):
-    """Same G9 evaluation in a subprocess with MD_GEMM_PP=1: every eligible conv / GEMM / GEGLU GEMM takes the ping-pong
-    (and persistent ping-pong) kernels that the automatic dispatch reserves for >= 225-tile launches (B = 32 frames at
-    config 2; G9's B = 4 alone would not select them) -- pinned to the reference's own prediction, not to a sibling kernel."""
+def test_g9_full_size_sp_kernels_vs_reference_golden(golden_dir, tmp_path):
+    """Same G9 evaluation in a subprocess with MD_GEMM_SP=1: every eligible conv / GEMM / GEGLU GEMM takes the persistent
+    one-wave-per-SIMD kernels (gemm_sp.h) that the automatic dispatch reserves for >= 192..512-tile launches (B = 32 frames at
+    config 2; G9's B = 4 alone selects them for the 96 x 96 convs only) -- pinned to the reference's own prediction, not to a
+    sibling kernel."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    out = str(tmp_path / "g9_pp.pt")
-    r = subprocess.run([sys.executable, os.path.join(here, "g9_pair.py"), out], env=dict(os.environ, MD_GEMM_PP="1"),
+    out = str(tmp_path / "g9_sp.pt")
+    r = subprocess.run([sys.executable, os.path.join(here, "g9_pair.py"), out], env=dict(os.environ, MD_GEMM_SP="1"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     pred = torch.load(out)
