@@ -86,6 +86,38 @@ __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
   const float2_t m = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
   return m - ax * r;
 }
+// The same arithmetic on N independent pairs, stage by stage (pinned): a kernel with ONE wave per SIMD has nobody to cover the
+// 6 + 4 + 1 + 1 dependent packed operations of a single chain (the compiler emits them back to back with s_nop between them).
+template <int N>
+__device__ __forceinline__ void gelu_fast2_x(float2_t (&x)[N]) {
+  float2_t ax[N], p[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    ax[c] = float2_t{__builtin_fabsf(x[c].x), __builtin_fabsf(x[c].y)};
+    p[c] = float2_t{5.621299664e-06f, 5.621299664e-06f} * ax[c] + float2_t{5.105520901e-05f, 5.105520901e-05f};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#define MD_GELU_STAGE(K)                                            \
+  _Pragma("unroll") for (int c = 0; c < N; ++c) p[c] = p[c] * ax[c] + float2_t{K, K}; \
+  __builtin_amdgcn_sched_barrier(0);
+  MD_GELU_STAGE(3.968613701e-05f)
+  MD_GELU_STAGE(3.422739239e-03f)
+  MD_GELU_STAGE(2.207699846e-02f)
+  MD_GELU_STAGE(5.207516304e-02f)
+  MD_GELU_STAGE(1.044273782e+00f)
+#undef MD_GELU_STAGE
+#pragma unroll
+  for (int sq = 0; sq < 4; ++sq) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) p[c] = p[c] * p[c];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) p[c] = float2_t{__builtin_amdgcn_rcpf(p[c].x), __builtin_amdgcn_rcpf(p[c].y)};
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < N; ++c) x[c] = float2_t{fmaxf(x[c].x, 0.f), fmaxf(x[c].y, 0.f)} - ax[c] * p[c];
+}
 __device__ __forceinline__ float gelu_fast(float x) {
   const float2_t g = gelu_fast2(float2_t{x, x});
   return g.x;
@@ -577,8 +609,31 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // parity tests: MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).  (The two-waves-per-SIMD ping-pong
   // kernels of rounds 1-2, gemm_pp.h, lost every shape they used to win to gemm_sp_kernel and were removed in round 3.)
   static const int sp = env_int("MD_GEMM_SP", 2);
-  if (sp == 1 && sp_eligible<CONV, GEGLU>(p)) {
-    launch_sp<CONV, GEGLU>(p, stream);
+  // gemm_sp_kernel's tile: 256 x 256 for GEGLU; 192 x 320 or 192 x 256 otherwise, whichever needs less time by the model
+  // rounds x (T0 + K tiles x t_k): rounds = ceil(tiles / CUs) of the persistent grid, T0 ~ 4 us per output tile outside its K loop,
+  // t_k = 1.56 / 1.28 us per 64-deep K tile (15 / 12 MFMAs per k-step at the measured ~72 % duty; profiles/r03_ab_gemm_sp_tiles.log).
+  // N = 1280 on M = 18 432 tokens: 384 tiles of 192 x 320 are 1.5 rounds (2 paid), 480 tiles of 192 x 256 are 1.9.
+  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B builds only
+  int nt = GEGLU ? 4 : 0;
+  if constexpr (!GEGLU) {
+    const int ncu = md_device_cus();
+    auto cost = [&](int bn, double tk) {
+      const long tiles = (long)cdiv(p.M, 192) * (p.N / bn);
+      return (double)cdiv(tiles, ncu) * (4.0 + (p.K / 64) * tk);
+    };
+    const bool ok5 = force_nt != 4 && sp_eligible<CONV, false, 5>(p), ok4 = force_nt != 5 && sp_eligible<CONV, false, 4>(p);
+    const double c5 = ok5 ? cost(320, 1.56) : 1e30, c4 = ok4 ? cost(256, 1.28) : 1e30;
+    if (ok5 || ok4) nt = c4 < c5 ? 4 : 5;
+  } else if (!sp_eligible<CONV, true>(p)) {
+    nt = 0;
+  }
+  auto run_sp = [&]() {
+    if constexpr (GEGLU) launch_sp<CONV, true>(p, stream);
+    else if (nt == 4) launch_sp<CONV, false, 4>(p, stream);
+    else launch_sp<CONV, false, 5>(p, stream);
+  };
+  if (sp == 1 && nt) {
+    run_sp();
     return;
   }
   // 1. HBM-bound short-K projections on long token matrices: W-stationary streaming kernel (gemm_ws.h), plain and GEGLU (K = 320)
@@ -595,15 +650,15 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
       return;
     }
   }
-  // 2. one-wave-per-SIMD flavour (gemm_sp.h): every 3x3 conv with at least 192 tiles of 192 x 320 (+3..37 % over the round-2 ping-pong /
-  //    128 x 128 kernels; the 12 x 12 level's 96 tiles run 17 % slower), GEGLU GEMMs with K >= 640 (+4..16 %), plain GEMMs with
-  //    at least 512 tiles (+4..20 %) or at least 256 tiles and K >= 2560 (+5..14 %); M = 18 432 x N = 1280 x K = 1280 (384 tiles =
-  //    1.5 rounds of 256 CUs) stays on the 128 x 128 kernel (-3..-7 %)
-  if (sp > 0 && sp_eligible<CONV, GEGLU>(p)) {
-    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : 192) * (p.N / (GEGLU ? 256 : 320));
-    const bool pick = CONV ? tiles >= 192 : (GEGLU ? p.K >= 640 : (tiles >= 512 || (tiles >= 256 && p.K >= 2560)));
+  // 2. one-wave-per-SIMD flavour (gemm_sp.h), same-box table in profiles/r03_ab_gemm_sp_tiles.log: every 3x3 conv and every plain
+  //    GEMM with K >= 640 that gives it at least 112 tiles (with the 192 x 256 tile the 12 x 12 level's 120 tiles run +15..25 % over
+  //    the 128 x 128 kernel, M = 4608 GEMMs +1..18 %, M = 18 432 x N = 1280 +19..34 %); GEGLU GEMMs with K >= 640 (+24..29 %; at
+  //    K = 320 the W-stationary kernel above is 9 % faster)
+  if (sp > 0 && nt) {
+    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : 192) * (p.N / (64 * nt));
+    const bool pick = GEGLU ? p.K >= 640 : (tiles >= 112 && (CONV || p.K >= 640));
     if (pick) {
-      launch_sp<CONV, GEGLU>(p, stream);
+      run_sp();
       return;
     }
   }

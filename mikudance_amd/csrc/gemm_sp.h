@@ -59,26 +59,81 @@ __device__ __forceinline__ float sp_acc(const floatx16& a, int r) {
 // (lc = lane % 32, hi = lane / 32) holds, for output row mw + 32 i + lc, the columns 8 g + 4 hi + {0..3}, g = 0..3 of every
 // 32-column sub-tile j.  v_permlane32_swap pairs the 8-byte pieces of the two lane halves into 16-byte stores (guide T21) and
 // un-pairs 16-byte residual loads (same instruction: it is an involution).  act == ACT_NONE (launcher).  AGPR: read the accumulators
-// with sp_acc (gemm_sp_kernel: 240+ accumulators pinned in the accumulator file); false: plain reads (gemm_tw_kernel).
-template <int MT, int NT, bool RES, bool AGPR = true>
+// with sp_acc (gemm_sp_kernel: 240+ accumulators pinned in the accumulator file); false: plain reads.
+//
+// Order: sub-tile COLUMN by column (j outer, the MT rows inner).  The bias of a column is converted once for its MT sub-tiles,
+// and everything the column needs from memory (bias, residual, row-broadcast term) is requested ONE COLUMN AHEAD: with one wave
+// per SIMD nobody else covers a load's latency, and the first form of this epilogue (loads at the point of use, one sub-tile at a
+// time) exposed it 15 times per tile -- ~5 of the ~7.6 us a 192 x 320 tile spent outside its K loop.  RES / RA: residual /
+// row-broadcast operand present (absent operands cost nothing); with both, the row-broadcast values are requested at the top of
+// their own column instead (the registers for a second look-ahead set are not there).
+template <int MT, int NT, bool RES, bool RA>
+struct SpColumn {
+  half4_t b[4];                          // bias, columns 8 g + 4 hi + {0..3}
+  uint4 r[RES ? MT : 1][2];              // residual, 16-byte pieces (before the un-pairing swap)
+  half4_t a[RA ? MT : 1][4];             // row-broadcast term
+};
+
+template <int MT, int NT, bool RES, bool RA, bool AGPR = true>
 __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][NT], int mw, int nw, int lc, int hi) {
-  const half_t* bias = p.bias ? p.bias : g_zero_cols;
+  constexpr bool RA_AHEAD = RA && !RES;
+  const half_t* bias = (p.bias ? p.bias : g_zero_cols) + nw + 4 * hi;
+  bool row_ok[MT];
+  const half_t* rrow[MT];
+  const half_t* arow[MT];
+  half_t* crow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = mw + i * 32 + lc;
-    const bool row_ok = m < p.M;
-    const int mc = row_ok ? m : p.M - 1;
-    const half_t* ra = p.rowadd ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra : g_zero_cols;
-    const half_t* rrow = RES ? p.residual + (size_t)mc * p.ldr : nullptr;
-    half_t* crow = p.C + (size_t)mc * p.ldc;
+    row_ok[i] = m < p.M;
+    const int mc = row_ok[i] ? m : p.M - 1;
+    rrow[i] = RES ? p.residual + (size_t)mc * p.ldr + nw + 8 * hi : nullptr;
+    arow[i] = RA ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra + nw + 4 * hi : nullptr;
+    crow[i] = p.C + (size_t)mc * p.ldc + nw + 8 * hi;
+  }
+  SpColumn<MT, NT, RES, RA> col[2];
+  auto request = [&](SpColumn<MT, NT, RES, RA>& d, int j, bool ahead) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int nc = nw + j * 32;                                  // first column of this 32-column sub-tile
+    for (int gi = 0; gi < 4; ++gi) d.b[gi] = *reinterpret_cast<const half4_t*>(bias + j * 32 + 8 * gi);
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) d.r[i][pr] = *reinterpret_cast<const uint4*>(rrow[i] + j * 32 + 16 * pr);
+    }
+    if constexpr (RA) {
+      if (ahead == RA_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) d.a[i][gi] = *reinterpret_cast<const half4_t*>(arow[i] + j * 32 + 8 * gi);
+      }
+    }
+  };
+  request(col[0], 0, true);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    SpColumn<MT, NT, RES, RA>& c = col[j & 1];
+    if (j + 1 < NT) request(col[(j + 1) & 1], j + 1, true);
+    if constexpr (RA && !RA_AHEAD) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) c.a[i][gi] = *reinterpret_cast<const half4_t*>(arow[i] + j * 32 + 8 * gi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float bf[4][4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bf[gi][e] = (float)c.b[gi][e];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
       unsigned rp[4][2];
       if constexpr (RES) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          const uint4 r4 = *reinterpret_cast<const uint4*>(rrow + nc + 16 * pr + 8 * hi);
+          const uint4 r4 = c.r[i][pr];
           const auto s0 = __builtin_amdgcn_permlane32_swap(r4.x, r4.z, false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(r4.y, r4.w, false, false);
           rp[2 * pr][0] = s0[0]; rp[2 * pr][1] = s1[0];
@@ -88,12 +143,12 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
       unsigned w[4][2];
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
-        const int c = nc + 8 * gi + 4 * hi;
-        const half4_t bv = *reinterpret_cast<const half4_t*>(bias + c);
-        const half4_t av = *reinterpret_cast<const half4_t*>(ra + c);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (AGPR ? sp_acc(acc[i][j], 4 * gi + e) : acc[i][j][4 * gi + e]) + (float)bv[e] + (float)av[e];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (AGPR ? sp_acc(acc[i][j], 4 * gi + e) : acc[i][j][4 * gi + e]) + bf[gi][e];
+          if constexpr (RA) v[e] += (float)c.a[i][gi][e];
+        }
         if constexpr (RES) {
           half4_t rv;
           __builtin_memcpy(&rv, rp[gi], 8);
@@ -107,9 +162,9 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
       for (int pr = 0; pr < 2; ++pr) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
-        if (row_ok) {
+        if (row_ok[i]) {
           const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
-          *reinterpret_cast<uint4*>(crow + nc + 16 * pr + 8 * hi) = v4;
+          *reinterpret_cast<uint4*>(crow[i] + j * 32 + 16 * pr) = v4;
         }
       }
       __builtin_amdgcn_sched_barrier(0);                           // one sub-tile at a time: keeps the live ranges short
@@ -124,7 +179,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;        // 128-byte rows, 8 rows per DMA piece
   constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows (6 / 8), W rows (10 / 8)
-  static_assert(PA + PB == 16 && PB >= 6, "the issue schedule below places 6 + 4 + 3 + 3 pieces per K tile, W first");
+  static_assert((PA + PB == 16 || PA + PB == 14) && PB >= 6, "the issue schedule below places 6 + 4 + n + n pieces per K tile, W first");
+  constexpr int NPL = (PA + PB - 10) / 2;                // pieces in each of the last two k-steps of the schedule: 3 (16 pieces) / 2 (14)
   static_assert(!GEGLU || NT % 2 == 0, "GEGLU pairs 32-column sub-tiles (2q, 2q+1) of a wave");
   constexpr int ASZ = BM * ROWB, WSZ = BN * ROWB, WBASE = 3 * ASZ;        // ring: A slots 0..2, then W slots 0..1
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
       if (!(SP_ABL & 2)) {                                                                                  \
-        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? 3 : 4);                                         \
+        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? 3 : ((NP) == 3 ? 4 : 6));                       \
         if (k % STRIDE == 1 && k / STRIDE < (NP)) {                                                         \
           issue_q((Q0) + k / STRIDE);                                                                       \
           __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -330,8 +386,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #define SP_BODY(ZERO)                                                                                       \
   {                                                                                                         \
     SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, 6, 4)                                                      \
-    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, 10, 3)                                                    \
-    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, 13, 3)                                                    \
+    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, 10, NPL)                                                  \
+    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, 10 + NPL, NPL)                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     if (!(SP_ABL & 8)) wait_vmcnt<PA>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
     if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier();                                                        \
@@ -360,33 +416,36 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #pragma unroll
         for (int q = 0; q < NT / 2; ++q) {
           const int nc = n0 + wn * (32 * NT) + q * 64;
-          half4_t bh[4], bg[4];
+          const half_t* bias = (p.bias ? p.bias : g_zero_cols) + nc + 4 * hi;
+          float2_t bh[8], bg[8];                                  // pair c = 2 gi + e / 2: columns 8 gi + 4 hi + {e, e + 1}
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi) {
-            bh[gi] = half4_t{0, 0, 0, 0};
-            bg[gi] = half4_t{0, 0, 0, 0};
-            if (p.bias) {
-              bh[gi] = *reinterpret_cast<const half4_t*>(p.bias + nc + 8 * gi + 4 * hi);
-              bg[gi] = *reinterpret_cast<const half4_t*>(p.bias + nc + 32 + 8 * gi + 4 * hi);
-            }
+            const half4_t h4 = *reinterpret_cast<const half4_t*>(bias + 8 * gi);
+            const half4_t g4 = *reinterpret_cast<const half4_t*>(bias + 32 + 8 * gi);
+            bh[2 * gi] = float2_t{(float)h4[0], (float)h4[1]};
+            bh[2 * gi + 1] = float2_t{(float)h4[2], (float)h4[3]};
+            bg[2 * gi] = float2_t{(float)g4[0], (float)g4[1]};
+            bg[2 * gi + 1] = float2_t{(float)g4[2], (float)g4[3]};
           }
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * (32 * MT) + i * 32 + lc;
             const int mc = m < p.M ? m : p.M - 1;
             half_t* drow = p.C + (size_t)mc * p.ldc + (nc >> 1);
+            float2_t gl[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              gl[c] = float2_t{sp_acc(acc[i][2 * q + 1], 2 * c), sp_acc(acc[i][2 * q + 1], 2 * c + 1)} + bg[c];
+            __builtin_amdgcn_sched_barrier(0);
+            gelu_fast2_x<8>(gl);                                   // the eight chains of the row side by side
+            __builtin_amdgcn_sched_barrier(0);
             unsigned w[4][2];
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-              half4_t o;
-#pragma unroll
-              for (int e = 0; e < 4; e += 2) {
-                const float2_t gl = gelu_fast2(float2_t{sp_acc(acc[i][2 * q + 1], 4 * gi + e) + (float)bg[gi][e],
-                                                        sp_acc(acc[i][2 * q + 1], 4 * gi + e + 1) + (float)bg[gi][e + 1]});
-                o[e] = (half_t)((sp_acc(acc[i][2 * q], 4 * gi + e) + (float)bh[gi][e]) * gl.x);
-                o[e + 1] = (half_t)((sp_acc(acc[i][2 * q], 4 * gi + e + 1) + (float)bh[gi][e + 1]) * gl.y);
-              }
-              __builtin_memcpy(w[gi], &o, 8);
+            for (int c = 0; c < 8; ++c) {
+              const float2_t hv = (float2_t{sp_acc(acc[i][2 * q], 2 * c), sp_acc(acc[i][2 * q], 2 * c + 1)} + bh[c]) * gl[c];
+              typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+              const h2_t o = {(half_t)hv.x, (half_t)hv.y};
+              __builtin_memcpy(&w[c >> 1][c & 1], &o, 4);
             }
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
@@ -401,9 +460,12 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
           }
         }
       } else {
-        // bias and the row-broadcast term are always added (absent: a page of zeros, pitch 0), the residual splits the code once
-        if (p.residual) sp_plain_epilogue<MT, NT, true>(p, acc, m0 + wm * (32 * MT), n0 + wn * (32 * NT), lc, hi);
-        else sp_plain_epilogue<MT, NT, false>(p, acc, m0 + wm * (32 * MT), n0 + wn * (32 * NT), lc, hi);
+        // the bias is always added (absent: a page of zeros); residual and row-broadcast operand split the code (uniform branches)
+        const int mw = m0 + wm * (32 * MT), nw = n0 + wn * (32 * NT);
+        if (p.residual && p.rowadd) sp_plain_epilogue<MT, NT, true, true>(p, acc, mw, nw, lc, hi);
+        else if (p.residual) sp_plain_epilogue<MT, NT, true, false>(p, acc, mw, nw, lc, hi);
+        else if (p.rowadd) sp_plain_epilogue<MT, NT, false, true>(p, acc, mw, nw, lc, hi);
+        else sp_plain_epilogue<MT, NT, false, false>(p, acc, mw, nw, lc, hi);
       }
     }
   }
@@ -413,9 +475,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #endif
 }
 
-template <bool CONV, bool GEGLU>
+template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5>
 static bool sp_eligible(const GemmParams& p) {
-  constexpr int BN = GEGLU ? 256 : 320;
+  constexpr int BN = 64 * NT;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (p.transpose_out || p.N % BN != 0 || p.K % 64 != 0 || p.K < 128 || p.N > 16384) return false;
   if (!GEGLU && p.act != ACT_NONE) return false;
@@ -431,9 +493,9 @@ static bool sp_eligible(const GemmParams& p) {
   return true;
 }
 
-template <bool CONV, bool GEGLU>
+template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5>
 static void launch_sp(GemmParams& p, hipStream_t stream) {
-  constexpr int MT = GEGLU ? 4 : 3, NT = GEGLU ? 4 : 5;
+  constexpr int MT = GEGLU ? 4 : 3;
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128;          // A ring of three, W ring of two 64-deep K tiles
   md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);

@@ -11,14 +11,10 @@
 #ifndef GN_THREADS
 #define GN_THREADS 512
 #endif
-#ifndef MD_NT_STORES
-#define MD_NT_STORES 0   // A/B build: 1 = non-temporal stores for the streamed outputs of GroupNorm-apply and LayerNorm
-#endif
+// Plain stores on purpose: non-temporal stores for the streamed outputs measured +2..16 % on these kernels alone and -0.6 % end to
+// end (the consumer of a normalised tensor is the very next kernel; profiles/r03_ab_norm_nt_stores.log).
 template <typename T>
-__device__ __forceinline__ void norm_store(T* p, const T& v) {
-  if (MD_NT_STORES) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
+__device__ __forceinline__ void norm_store(T* p, const T& v) { *p = v; }
 #ifndef GN_SLAB
 #define GN_SLAB 32      // rows per row-lane and slab (same-box sweep on MI355X: 8: -35 %, 16: baseline, 24-32: +9 ... +20 %, 64: -8 %)
 #endif

@@ -38,7 +38,9 @@ d = lambda t: t.to(dev)
 # plain GEMM, N % 320 == 0: K from 4 ring tiles (the ring depth) to 90, ragged M, several column tiles; the last two give the
 # persistent kernel 2-3 output tiles per workgroup (57 600 / 192 = 300 tiles, 100 000 / 192 -> 521 tiles, ragged; 105 x 4 tiles in grouped order)
 for M, N, K in [(256, 320, 128), (1000, 320, 192), (77, 640, 256), (2048, 320, 320), (700, 1280, 1280), (4096, 640, 2880),
-                (57600, 320, 256), (100000, 320, 192), (20000, 1280, 128)]:
+                (57600, 320, 256), (100000, 320, 192), (20000, 1280, 128),
+                # N % 256 == 0 only: the 192 x 256 tile (14 DMA pieces per wave and K tile instead of 16)
+                (256, 256, 128), (1000, 512, 192), (77, 768, 256), (3000, 1024, 1280), (57600, 256, 256), (30000, 1280, 320)]:
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     check(f"gemm {M}x{N}x{K}", lambda: ops.gemm(d(a), d(w)), a.float() @ w.float().t())
 
@@ -51,22 +53,26 @@ assert torch.equal(out.cpu().float(), w.float().t()), "identity"
 print("ok  identity")
 
 # epilogues
-M, N, K = 900, 640, 256
-a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
-bias, res, radd = rnd(N, seed=5), rnd(M, N, seed=6), rnd(9, N, seed=7)
-base = a.float() @ w.float().t() + bias.float()
-check("bias", lambda: ops.gemm(d(a), d(w), bias=d(bias)), base)
-check("silu", lambda: ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_SILU), F.silu(base))
-check("relu", lambda: ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_RELU), F.relu(base))
-check("residual", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(res)), base + res.float())
-check("rowadd", lambda: ops.gemm(d(a), d(w), bias=d(bias), rowadd=d(radd), rows_per_group=100),
-      base + radd.float().repeat_interleave(100, 0))
-res_dev = d(res).clone()
-hs = res_dev.clone()
-ops.gemm(d(a), d(w), bias=d(bias), residual=hs, out=hs)                     # in place (blocks.py cross-attention)
-check("residual in place", lambda: hs, base + res.float())
-wide = rnd(M, 2 * K, seed=8)
-check("lda", lambda: ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t())
+for M, N, K in [(900, 640, 256), (900, 1280, 256), (900, 512, 256)]:
+    a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+    bias, res, radd = rnd(N, seed=5), rnd(M, N, seed=6), rnd(9, N, seed=7)
+    base = a.float() @ w.float().t() + bias.float()
+    check("bias", lambda: ops.gemm(d(a), d(w), bias=d(bias)), base)
+    check("silu", lambda: ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_SILU), F.silu(base))
+    check("relu", lambda: ops.gemm(d(a), d(w), bias=d(bias), act=ops.ACT_RELU), F.relu(base))
+    check("residual", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(res)), base + res.float())
+    check("rowadd", lambda: ops.gemm(d(a), d(w), bias=d(bias), rowadd=d(radd), rows_per_group=100),
+          base + radd.float().repeat_interleave(100, 0))
+    check("rowadd, no bias", lambda: ops.gemm(d(a), d(w), rowadd=d(radd), rows_per_group=100),
+          a.float() @ w.float().t() + radd.float().repeat_interleave(100, 0))
+    check("bias + residual + rowadd", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(res), rowadd=d(radd), rows_per_group=100),
+          base + res.float() + radd.float().repeat_interleave(100, 0))
+    res_dev = d(res).clone()
+    hs = res_dev.clone()
+    ops.gemm(d(a), d(w), bias=d(bias), residual=hs, out=hs)                     # in place (blocks.py cross-attention)
+    check("residual in place", lambda: hs, base + res.float())
+    wide = rnd(M, 2 * K, seed=8)
+    check("lda", lambda: ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t())
 
 # GEGLU (256 x 256 tiles; the last two cases give the persistent kernel 2-3 output tiles per workgroup, one of them ragged in M)
 for M, K, inner in [(200, 128, 256), (1500, 320, 1280), (300, 1280, 512), (10240, 128, 1024), (20000, 320, 1024)]:
@@ -78,6 +84,7 @@ for M, K, inner in [(200, 128, 256), (1500, 320, 1280), (300, 1280, 512), (10240
 
 # 3x3 convolutions with Cout % 320 == 0: padding, stride 2, folded 2x upsample, fused time embedding + residual
 for cin, cout, h, wd, stride, up in [(64, 320, 8, 8, 1, False), (320, 320, 24, 24, 1, False), (128, 640, 13, 11, 2, False),
+                                     (64, 256, 9, 7, 1, False), (128, 512, 24, 24, 2, False), (64, 1280, 24, 24, 1, False), (128, 256, 10, 10, 1, True),
                                      (64, 320, 6, 5, 1, True), (640, 320, 16, 16, 1, False), (64, 320, 96, 96, 1, False)]:
     B = 8 if h == 96 else 3      # 96 x 96 x 8 = 384 output tiles: the persistent kernel wraps
     x = rnd(B, cin, h, wd, seed=20)
