@@ -96,11 +96,14 @@ __device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, co
   const floatx4 h0 = *reinterpret_cast<const floatx4*>(s), h1 = *reinterpret_cast<const floatx4*>(s + 4);
   const floatx4 g0 = *reinterpret_cast<const floatx4*>(s + 32), g1 = *reinterpret_cast<const floatx4*>(s + 36);
   half8_t o;
+  float2_t gl[4];                         // pairs: the GELU polynomial runs on packed fp32, the four chains of a piece side by side
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {          // pairs: the GELU polynomial runs on packed fp32 (gelu_fast2)
-    const float2_t gl = gelu_fast2(float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]});
-    o[j] = (half_t)((h0[j] + q.bh[j]) * gl.x);
-    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gl.y);
+  for (int j = 0; j < 4; ++j) gl[j] = float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]};
+  gelu_fast2_x<4>(gl);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (half_t)((h0[j] + q.bh[j]) * gl[j].x);
+    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gl[j].y);
   }
   return o;
 }
