@@ -609,27 +609,31 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // parity tests: MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).  (The two-waves-per-SIMD ping-pong
   // kernels of rounds 1-2, gemm_pp.h, lost every shape they used to win to gemm_sp_kernel and were removed in round 3.)
   static const int sp = env_int("MD_GEMM_SP", 2);
-  // gemm_sp_kernel's tile: 256 x 256 for GEGLU; 192 x 320 or 192 x 256 otherwise, whichever needs less time by the model
+  // gemm_sp_kernel's tile: 256 x 256 for GEGLU; 192 x 320, 192 x 256 or 128 x 256 otherwise, whichever needs least time by the model
   // rounds x (T0 + K tiles x t_k): rounds = ceil(tiles / CUs) of the persistent grid, T0 ~ 4 us per output tile outside its K loop,
-  // t_k = 1.56 / 1.28 us per 64-deep K tile (15 / 12 MFMAs per k-step at the measured ~72 % duty; profiles/r03_ab_gemm_sp_tiles.log).
-  // N = 1280 on M = 18 432 tokens: 384 tiles of 192 x 320 are 1.5 rounds (2 paid), 480 tiles of 192 x 256 are 1.9.
-  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B builds only
-  int nt = GEGLU ? 4 : 0;
+  // t_k = 1.56 / 1.28 / 0.95 us per 64-deep K tile (15 / 12 / 8 MFMAs per k-step; profiles/r03_ab_gemm_sp_tiles.log).
+  // N = 1280 on M = 18 432 tokens: 384 tiles of 192 x 320 are 1.5 rounds (2 paid), 480 tiles of 192 x 256 are 1.9;
+  // on M = 4608 (the 12 x 12 level) 120 tiles of 192 x 256 leave half of the CUs idle, 180 tiles of 128 x 256 less than a third.
+  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 pin 192 x 320 / 192 x 256 / 128 x 256
+  int nt = GEGLU ? 4 : 0;                                         // 5, 4: 192-row tiles; 2: 128 x 256
   if constexpr (!GEGLU) {
     const int ncu = md_device_cus();
-    auto cost = [&](int bn, double tk) {
-      const long tiles = (long)cdiv(p.M, 192) * (p.N / bn);
+    auto cost = [&](int bm, int bn, double tk) {
+      const long tiles = (long)cdiv(p.M, bm) * (p.N / bn);
       return (double)cdiv(tiles, ncu) * (4.0 + (p.K / 64) * tk);
     };
-    const bool ok5 = force_nt != 4 && sp_eligible<CONV, false, 5>(p), ok4 = force_nt != 5 && sp_eligible<CONV, false, 4>(p);
-    const double c5 = ok5 ? cost(320, 1.56) : 1e30, c4 = ok4 ? cost(256, 1.28) : 1e30;
-    if (ok5 || ok4) nt = c4 < c5 ? 4 : 5;
+    const bool ok5 = (force_nt == 0 || force_nt == 5) && sp_eligible<CONV, false, 5>(p);
+    const bool ok4 = sp_eligible<CONV, false, 4>(p);
+    const double c5 = ok5 ? cost(192, 320, 1.56) : 1e30, c4 = ok4 && (force_nt == 0 || force_nt == 4) ? cost(192, 256, 1.28) : 1e30,
+                 c2 = ok4 && (force_nt == 0 || force_nt == 2) ? cost(128, 256, 0.95) : 1e30;
+    if (c5 < 1e30 || c4 < 1e30 || c2 < 1e30) nt = c5 <= c4 && c5 <= c2 ? 5 : (c4 <= c2 ? 4 : 2);
   } else if (!sp_eligible<CONV, true>(p)) {
     nt = 0;
   }
   auto run_sp = [&]() {
     if constexpr (GEGLU) launch_sp<CONV, true>(p, stream);
     else if (nt == 4) launch_sp<CONV, false, 4>(p, stream);
+    else if (nt == 2) launch_sp<CONV, false, 4, 2>(p, stream);
     else launch_sp<CONV, false, 5>(p, stream);
   };
   if (sp == 1 && nt) {
@@ -655,7 +659,7 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   //    the 128 x 128 kernel, M = 4608 GEMMs +1..18 %, M = 18 432 x N = 1280 +19..34 %); GEGLU GEMMs with K >= 640 (+24..29 %; at
   //    K = 320 the W-stationary kernel above is 9 % faster)
   if (sp > 0 && nt) {
-    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : 192) * (p.N / (64 * nt));
+    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : (nt == 2 ? 128 : 192)) * (p.N / (nt == 5 ? 320 : 256));
     const bool pick = GEGLU ? p.K >= 640 : (tiles >= 112 && (CONV || p.K >= 640));
     if (pick) {
       run_sp();

@@ -179,8 +179,11 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;        // 128-byte rows, 8 rows per DMA piece
   constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows (6 / 8), W rows (10 / 8)
-  static_assert((PA + PB == 16 || PA + PB == 14) && PB >= 6, "the issue schedule below places 6 + 4 + n + n pieces per K tile, W first");
-  constexpr int NPL = (PA + PB - 10) / 2;                // pieces in each of the last two k-steps of the schedule: 3 (16 pieces) / 2 (14)
+  // issue schedule of a wave's PA + PB pieces per K tile over the four k-steps that follow the tile's barrier, W pieces first:
+  // 6 + 4 + 3 + 3 (16 pieces), 6 + 4 + 2 + 2 (14), 4 + 4 + 2 + 2 (12: the 128 x 256 tile has 8 MFMAs per k-step to hide them behind)
+  static_assert(PA + PB == 16 || PA + PB == 14 || PA + PB == 12, "issue schedule");
+  constexpr int NP0 = PA + PB == 12 ? 4 : 6, NP1 = 4, NP2 = (PA + PB - NP0 - NP1) / 2, NP3 = NP2;
+  static_assert(NP0 + NP1 + NP2 + NP3 == PA + PB && PB >= NP0, "issue schedule");
   static_assert(!GEGLU || NT % 2 == 0, "GEGLU pairs 32-column sub-tiles (2q, 2q+1) of a wave");
   constexpr int ASZ = BM * ROWB, WSZ = BN * ROWB, WBASE = 3 * ASZ;        // ring: A slots 0..2, then W slots 0..1
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,7 +352,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
       if (!(SP_ABL & 2)) {                                                                                  \
-        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? 3 : ((NP) == 3 ? 4 : 6));                       \
+        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? (MT * NT >= 12 ? 3 : 2) : ((NP) == 3 ? 4 : (MT * NT >= 12 ? 6 : 4))); \
+        static_assert(STRIDE * ((NP) - 1) + 1 < MT * NT, "a DMA piece per MFMA gap at most");               \
         if (k % STRIDE == 1 && k / STRIDE < (NP)) {                                                         \
           issue_q((Q0) + k / STRIDE);                                                                       \
           __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -371,8 +375,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     advance_a();
   }
 #pragma unroll
-  for (int q = 0; q < 6; ++q) issue_q(q);
-  wait_vmcnt<PA + 6>();                                              // this wave's pieces of W(0) and A(0)
+  for (int q = 0; q < NP0; ++q) issue_q(q);
+  wait_vmcnt<PA + NP0>();                                              // this wave's pieces of W(0) and A(0)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < MT; ++i) fa0[i] = *reinterpret_cast<const half8_t*>(smem + a_rd[0][i]);
@@ -385,16 +389,16 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   // scratch on every iteration.
 #define SP_BODY(ZERO)                                                                                       \
   {                                                                                                         \
-    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, 6, 4)                                                      \
-    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, 10, NPL)                                                  \
-    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, 10 + NPL, NPL)                                            \
+    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, NP0, NP1)                                                  \
+    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, NP0 + NP1, NP2)                                           \
+    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, NP0 + NP1 + NP2, NP3)                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     if (!(SP_ABL & 8)) wait_vmcnt<PA>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
     if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier();                                                        \
     ca += ASZ;                                                                                              \
     if (ca == 3 * ASZ) ca = 0;                                                                              \
     cw ^= WSZ;                                                                                              \
-    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 0, false, 0, 6)                                                     \
+    SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 0, false, 0, NP0)                                                   \
   }
 
   int ca = 0, cw = 0;                               // A / W slot offsets of the tile being multiplied
@@ -493,9 +497,8 @@ static bool sp_eligible(const GemmParams& p) {
   return true;
 }
 
-template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5>
+template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5, int MT = GEGLU ? 4 : 3>
 static void launch_sp(GemmParams& p, hipStream_t stream) {
-  constexpr int MT = GEGLU ? 4 : 3;
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128;          // A ring of three, W ring of two 64-deep K tiles
   md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
