@@ -43,6 +43,18 @@
 #define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
 #endif
 
+#ifdef SP_TRACE
+// diagnostic build only (tools/build_ab.sh trace -DSP_TRACE, tools/sp_trace.py): shader-clock stamps of workgroup 0, every wave, its
+// first SP_TRACE_N K tiles; kept in the LDS left over by the ring and copied out when the kernel ends
+#define SP_TRACE_N 48
+__device__ unsigned long long g_sp_trace[4][SP_TRACE_N][5];
+#define SP_STAMP(S)                                                                                           \
+  if (!GEGLU && blockIdx.x == 0 && tr_kt < SP_TRACE_N && lane == 0)                                           \
+    *reinterpret_cast<unsigned long long*>(smem + (3 * BM + 2 * BN) * 128 + ((wave * SP_TRACE_N + tr_kt) * 5 + (S)) * 8) = __builtin_readcyclecounter();
+#else
+#define SP_STAMP(S)
+#endif
+
 // zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
 __device__ __attribute__((aligned(64))) half_t g_zero_cols[16384] = {};
 
@@ -389,19 +401,31 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   // scratch on every iteration.
 #define SP_BODY(ZERO)                                                                                       \
   {                                                                                                         \
+    SP_STAMP(0)                                                                                             \
     SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, NP0, NP1)                                                  \
+    SP_STAMP(1)                                                                                             \
     SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, NP0 + NP1, NP2)                                           \
+    SP_STAMP(2)                                                                                             \
     SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, NP0 + NP1 + NP2, NP3)                                     \
+    SP_STAMP(3)                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     if (!(SP_ABL & 8)) wait_vmcnt<PA>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
     if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier();                                                        \
+    SP_STAMP(4)                                                                                             \
     ca += ASZ;                                                                                              \
     if (ca == 3 * ASZ) ca = 0;                                                                              \
     cw ^= WSZ;                                                                                              \
     SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 0, false, 0, NP0)                                                   \
+    SP_TRACE_NEXT                                                                                           \
   }
 
   int ca = 0, cw = 0;                               // A / W slot offsets of the tile being multiplied
+#ifdef SP_TRACE
+  int tr_kt = 0;
+#define SP_TRACE_NEXT ++tr_kt;
+#else
+#define SP_TRACE_NEXT
+#endif
 #pragma unroll 1
   for (int ct = 0; ct < ntile; ++ct) {
     SP_BODY(true)
@@ -474,6 +498,14 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     }
   }
   wait_vmcnt<0>();                                                   // the DMA pieces issued past the last tile
+#ifdef SP_TRACE
+  if (!GEGLU && blockIdx.x == 0) {
+    __syncthreads();
+    for (int i = tid; i < 4 * SP_TRACE_N * 5; i += 256)
+      (&g_sp_trace[0][0][0])[i] = *reinterpret_cast<const unsigned long long*>(smem + (3 * BM + 2 * BN) * 128 + i * 8);
+  }
+#endif
+#undef SP_TRACE_NEXT
 #undef SP_BODY
 #undef SP_STEP
 #endif
@@ -500,7 +532,12 @@ static bool sp_eligible(const GemmParams& p) {
 template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5, int MT = GEGLU ? 4 : 3>
 static void launch_sp(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
+#ifdef SP_TRACE
+  constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128 + (GEGLU ? 0 : 4 * SP_TRACE_N * 5 * 8);
+  static_assert(smem <= 160 * 1024, "trace build: the stamps live behind the ring");
+#else
   constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128;          // A ring of three, W ring of two 64-deep K tiles
+#endif
   md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
   constexpr int group_m = 8;       // row-major order (1) measured 3-38 % slower on the wide-N shapes (profiles/r03_ab_gemm_sp.log)
   p.tiles_n = p.N / BN;
@@ -511,3 +548,9 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
   hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);
 }
+
+#ifdef SP_TRACE
+extern "C" int md_debug_sp_trace(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sp_trace), sizeof(unsigned long long) * 4 * SP_TRACE_N * 5);
+}
+#endif
