@@ -40,7 +40,8 @@
 // reads again), so every count is a compile-time constant; the kernel drains them before it ends.
 #pragma once
 #ifndef SP_ABL
-#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait
+#define SP_ABL 0   // diagnostic builds only (tools/build_ab.sh): 1 no barrier, 2 no DMA in the loop, 4 no fragment reads in the loop, 8 no vmcnt wait,
+                   // 16 every DMA piece re-reads the first K tile of the first rows (cache hits: issue cost without the memory system behind it)
 #endif
 
 #ifdef SP_TRACE
@@ -284,10 +285,10 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   set_sources_a(0);
   set_sources_w(0);
   auto issue_a = [&](int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + ia_slot * ASZ + (wave * PA + j) * 1024), 16, a_voff[j], (CONV ? ia_c0 : ia_k0) * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + ia_slot * ASZ + (wave * PA + j) * 1024), 16, (SP_ABL & 16) ? (unsigned)(lane * 16 + j * 1024) : a_voff[j], (SP_ABL & 16) ? 0 : (CONV ? ia_c0 : ia_k0) * 2, 0, 0);
   };
   auto issue_w = [&](int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem + WBASE + iw_slot * WSZ + (wave * PB + j) * 1024), 16, w_voff[j], iw_k0 * 2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(smem + WBASE + iw_slot * WSZ + (wave * PB + j) * 1024), 16, (SP_ABL & 16) ? (unsigned)(lane * 16 + j * 1024) : w_voff[j], (SP_ABL & 16) ? 0 : iw_k0 * 2, 0, 0);
   };
   auto advance_a = [&]() {
     ia_k0 += BK;

@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 os.environ["MD_GEMM_SP"] = "1"
 os.environ["MD_GEMM_SP_NT"] = "5"
-shutil.copy(os.path.join(root, "tools/ab/lib_trace.so"), os.path.join(root, "mikudance_amd/libmdance_hip.so"))
+shutil.copy(os.path.join(root, "tools/ab/lib_%s.so" % os.environ.get("SP_TRACE_LIB", "trace")), os.path.join(root, "mikudance_amd/libmdance_hip.so"))
 from mikudance_amd import ops, _lib  # noqa
 dev = torch.device("cuda")
 lib = _lib.load()
