@@ -43,6 +43,7 @@ struct GemmParams {
   int rows_per_group;
   int act;
   int transpose_out;
+  int bias_rows;          // gemm_sp_kernel on swapped operands (transposed output): bias[m] per output ROW instead of bias[n] per column
   // conv
   int Hin, Win, Cin, Hout, Wout, stride, upsample, pad;   // pad: zero rows/cols before the image (1, or 0 for the VAE downsampler)
   int tiles_n, tiles_total;
@@ -614,6 +615,30 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // t_k = 1.56 / 1.28 / 0.95 us per 64-deep K tile (15 / 12 / 8 MFMAs per k-step; profiles/r03_ab_gemm_sp_tiles.log).
   // N = 1280 on M = 18 432 tokens: 384 tiles of 192 x 320 are 1.5 rounds (2 paid), 480 tiles of 192 x 256 are 1.9;
   // on M = 4608 (the 12 x 12 level) 120 tiles of 192 x 256 leave half of the CUs idle, 180 tiles of 128 x 256 less than a third.
+  // Transposed output (V^T of the attention kernels, bias only): the same kernel on SWAPPED operands -- C^T[N][M] = W[N][K] . A[M][K]^T
+  // is a plain GEMM whose "A" is the weight, whose "W" is the token matrix (row pitch K required) and whose bias runs along the
+  // output rows; M must be a multiple of 256 (it is the swapped problem's N).
+  if constexpr (!CONV && !GEGLU) {
+    if (p.transpose_out && sp > 0 && p.lda == p.K && p.act == ACT_NONE && !p.residual && !p.rowadd) {
+      GemmParams q = p;
+      q.A = p.W; q.W = p.A; q.lda = p.K; q.M = p.N; q.N = p.M; q.transpose_out = 0; q.bias_rows = 1;
+      if (sp_eligible<false, false, 4>(q)) {
+        const int ncu = md_device_cus();
+        auto cost = [&](int bm, double tk) {
+          const long tiles = (long)cdiv(q.M, bm) * (q.N / 256);
+          return (double)cdiv(tiles, ncu) * (4.0 + (q.K / 64) * tk);
+        };
+        static const int force_nt_t = env_int("MD_GEMM_SP_NT", 0);
+        const bool small = force_nt_t == 2 || (force_nt_t != 4 && cost(128, 0.95) < cost(192, 1.28));
+        const long tiles = (long)cdiv(q.M, small ? 128 : 192) * (q.N / 256);
+        if (sp == 1 || (tiles >= 112 && q.K >= 256)) {
+          if (small) launch_sp<false, false, 4, 2>(q, stream);
+          else launch_sp<false, false, 4>(q, stream);
+          return;
+        }
+      }
+    }
+  }
   static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 pin 192 x 320 / 192 x 256 / 128 x 256
   int nt = GEGLU ? 4 : 0;                                         // 5, 4: 192-row tiles; 2: 128 x 256
   if constexpr (!GEGLU) {
@@ -731,7 +756,7 @@ extern "C" int md_gemm_f16(const void* A, int lda, const void* W, void* C, int l
   p.A = (const half_t*)A; p.W = (const half_t*)W; p.C = (half_t*)C;
   p.bias = (const half_t*)bias; p.residual = (const half_t*)residual; p.rowadd = (const half_t*)rowadd;
   p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldra = ldra;
-  p.M = M; p.N = N; p.K = K; p.rows_per_group = rows_per_group; p.act = act; p.transpose_out = transpose_out;
+  p.M = M; p.N = N; p.K = K; p.rows_per_group = rows_per_group; p.act = act; p.transpose_out = transpose_out; p.bias_rows = 0;
   return launch_gemm(p, false, (hipStream_t)stream);
 }
 

@@ -87,10 +87,12 @@ struct SpColumn {
   half4_t a[RA ? MT : 1][4];             // row-broadcast term
 };
 
-template <int MT, int NT, bool RES, bool RA, bool AGPR = true>
+template <int MT, int NT, bool RES, bool RA, bool AGPR = true, bool RB = false>
 __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][NT], int mw, int nw, int lc, int hi) {
+  // RB: the bias belongs to the output ROW (the launcher swapped the operands to produce a transposed output: V^T for attention)
   constexpr bool RA_AHEAD = RA && !RES;
-  const half_t* bias = (p.bias ? p.bias : g_zero_cols) + nw + 4 * hi;
+  const half_t* bias = (p.bias && !RB ? p.bias : g_zero_cols) + (RB ? 0 : nw + 4 * hi);
+  float rowb[MT];
   bool row_ok[MT];
   const half_t* rrow[MT];
   const half_t* arow[MT];
@@ -100,14 +102,17 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
     const int m = mw + i * 32 + lc;
     row_ok[i] = m < p.M;
     const int mc = row_ok[i] ? m : p.M - 1;
+    rowb[i] = RB && p.bias ? (float)p.bias[mc] : 0.f;
     rrow[i] = RES ? p.residual + (size_t)mc * p.ldr + nw + 8 * hi : nullptr;
     arow[i] = RA ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra + nw + 4 * hi : nullptr;
     crow[i] = p.C + (size_t)mc * p.ldc + nw + 8 * hi;
   }
   SpColumn<MT, NT, RES, RA> col[2];
   auto request = [&](SpColumn<MT, NT, RES, RA>& d, int j, bool ahead) {
+    if constexpr (!RB) {
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) d.b[gi] = *reinterpret_cast<const half4_t*>(bias + j * 32 + 8 * gi);
+      for (int gi = 0; gi < 4; ++gi) d.b[gi] = *reinterpret_cast<const half4_t*>(bias + j * 32 + 8 * gi);
+    }
     if constexpr (RES) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -139,7 +144,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bf[gi][e] = (float)c.b[gi][e];
+      for (int e = 0; e < 4; ++e) bf[gi][e] = RB ? 0.f : (float)c.b[gi][e];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       unsigned rp[4][2];
@@ -159,7 +164,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = (AGPR ? sp_acc(acc[i][j], 4 * gi + e) : acc[i][j][4 * gi + e]) + bf[gi][e];
+          v[e] = (AGPR ? sp_acc(acc[i][j], 4 * gi + e) : acc[i][j][4 * gi + e]) + (RB ? rowb[i] : bf[gi][e]);
           if constexpr (RA) v[e] += (float)c.a[i][gi][e];
         }
         if constexpr (RES) {
@@ -241,15 +246,20 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   unsigned a_img[PA];                              // conv: byte offset of the lane's image + its 16-byte slot
   int ia_it = 0, ia_kt = 0, ia_k0 = 0, ia_c0 = 0, ia_ky = 0, ia_kx = 0, ia_slot = 0;   // A stream: next tile to issue
   int iw_it = 0, iw_kt = 0, iw_k0 = 0, iw_slot = 0;                                   // W stream
-  auto conv_tap_offsets = [&]() {                  // once per filter tap (every Cin / 64 K tiles), not per piece
+  // per-lane offset of piece j for filter tap (ky, kx): once per tap (every Cin / 64 K tiles), not per K tile.  All pieces at once
+  // at the tap change: the burst holds the MFMAs up for ~440 cycles (profiles/r03_sp_trace.log), but spreading it over the piece
+  // gaps (each piece computing its next offset behind its last issue of the old tap) measured 3-7 % SLOWER on every conv
+  // (profiles/r03_ab_transposed_sp.log): a scalar test per piece costs more than the burst per tap.
+  auto conv_tap_offset = [&](int j, int ky, int kx) {
+    const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
+    const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
+    const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
+    const unsigned off = (((unsigned)(iy >> p.upsample) * (unsigned)p.Win + (unsigned)(ix >> p.upsample)) * (unsigned)p.Cin) * 2u + a_img[j];
+    a_voff[j] = ok ? off : OOB;
+  };
+  auto conv_tap_offsets = [&]() {
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-      const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
-      const int iy = a_oy[j] + ia_ky, ix = a_ox[j] + ia_kx;
-      const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
-      const unsigned off = (((unsigned)(iy >> p.upsample) * (unsigned)p.Win + (unsigned)(ix >> p.upsample)) * (unsigned)p.Cin) * 2u + a_img[j];
-      a_voff[j] = ok ? off : OOB;
-    }
+    for (int j = 0; j < PA; ++j) conv_tap_offset(j, ia_ky, ia_kx);
   };
   auto set_sources_a = [&](int i) {
     int m0, n0;
@@ -491,7 +501,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       } else {
         // the bias is always added (absent: a page of zeros); residual and row-broadcast operand split the code (uniform branches)
         const int mw = m0 + wm * (32 * MT), nw = n0 + wn * (32 * NT);
-        if (p.residual && p.rowadd) sp_plain_epilogue<MT, NT, true, true>(p, acc, mw, nw, lc, hi);
+        if (p.bias_rows) sp_plain_epilogue<MT, NT, false, false, true, true>(p, acc, mw, nw, lc, hi);
+        else if (p.residual && p.rowadd) sp_plain_epilogue<MT, NT, true, true>(p, acc, mw, nw, lc, hi);
         else if (p.residual) sp_plain_epilogue<MT, NT, true, false>(p, acc, mw, nw, lc, hi);
         else if (p.rowadd) sp_plain_epilogue<MT, NT, false, true>(p, acc, mw, nw, lc, hi);
         else sp_plain_epilogue<MT, NT, false, false>(p, acc, mw, nw, lc, hi);
@@ -516,7 +527,9 @@ template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5>
 static bool sp_eligible(const GemmParams& p) {
   constexpr int BN = 64 * NT;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (p.transpose_out || p.N % BN != 0 || p.K % 64 != 0 || p.K < 128 || p.N > 16384) return false;
+  // N <= 16384: the zero page standing in for absent column operands; the row-bias form (swapped operands) has no column operands
+  if (p.transpose_out || p.N % BN != 0 || p.K % 64 != 0 || p.K < 128 || (p.N > 16384 && !p.bias_rows)) return false;
+  if (p.bias_rows && (p.residual || p.rowadd || CONV || GEGLU)) return false;
   if (!GEGLU && p.act != ACT_NONE) return false;
   if (CONV && p.Cin % 64 != 0) return false;
   // the DMA pieces address A and W through buffer descriptors with 32-bit byte offsets; offsets from 2^31 up mean "outside"
@@ -524,7 +537,7 @@ static bool sp_eligible(const GemmParams& p) {
                                           : ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2;
   if (a_bytes >= (1ull << 31) || (unsigned long long)p.N * p.K * 2 >= (1ull << 31)) return false;
   if (!al16(p.C) || p.ldc % 8 != 0) return false;
-  if (p.bias && !al16(p.bias)) return false;
+  if (p.bias && !p.bias_rows && !al16(p.bias)) return false;
   if (p.residual && (!al16(p.residual) || p.ldr % 8 != 0)) return false;
   if (p.rowadd && (!al16(p.rowadd) || p.ldra % 8 != 0)) return false;
   return true;

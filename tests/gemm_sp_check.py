@@ -74,6 +74,14 @@ for M, N, K in [(900, 640, 256), (900, 1280, 256), (900, 512, 256)]:
     wide = rnd(M, 2 * K, seed=8)
     check("lda", lambda: ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t())
 
+# transposed output (V^T for the attention kernels): the same kernels on swapped operands, bias along the output rows; M % 256 == 0
+for M, N, K, with_bias in [(2048, 320, 320, False), (8192, 640, 640, True), (4608, 1280, 1280, False), (512, 1280, 256, True), (73728, 320, 320, True)]:
+    a, w = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5)
+    bias = rnd(N, seed=33) if with_bias else None
+    ref = (a.float() @ w.float().t() + (bias.float() if with_bias else 0)).t()
+    check(f"transposed {M}x{N}x{K}{' +bias' if with_bias else ''}",
+          lambda: ops.gemm(d(a), d(w), bias=d(bias) if with_bias else None, transpose_out=True), ref)
+
 # GEGLU (256 x 256 tiles; the last two cases give the persistent kernel 2-3 output tiles per workgroup, one of them ragged in M)
 for M, K, inner in [(200, 128, 256), (1500, 320, 1280), (300, 1280, 512), (10240, 128, 1024), (20000, 320, 1024)]:
     a = rnd(M, K, seed=11)

@@ -51,6 +51,12 @@ def main(which):
             ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=r, out=o))
             byts = 2.0 * (M * K + M * N * (2 if res else 1))
             out[f"gemm {M}x{N}x{K}{' +res' if res else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9, byts / ms / 1e6)
+    if "tgemm" in which:       # transposed-output projections (V^T for the attention kernels)
+        for M, N, K in [(294912, 320, 320), (73728, 640, 640), (18432, 1280, 1280), (4608, 1280, 1280), (147456, 320, 320)]:
+            a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+            o = torch.empty((N, M), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.gemm(a, w, transpose_out=True, out=o))
+            out[f"gemm {M}x{N}x{K} T"] = (ms, 2.0 * M * N * K / ms / 1e9)
     if "small" in which:       # the 12x12 level (M = 4608): fewer workgroups than CU slots
         for M, N, K, geglu in [(4608, 1280, 1280, False), (4608, 10240, 1280, True), (4608, 1280, 5120, False), (4608, 2560, 1280, False)]:
             a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
