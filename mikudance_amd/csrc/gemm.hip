@@ -604,12 +604,16 @@ static bool ws_eligible(const GemmParams& p) {
   return al(p.A) && al(p.W) && al(p.C) && al(p.bias) && al(p.residual) && al(p.rowadd);
 }
 
-template <bool CONV, bool GEGLU>
-static void launch_any(GemmParams& p, hipStream_t stream) {
+// Plan codes (returned by dispatch_any; md_gemm_plan / md_conv3x3_plan expose them so that the table is testable without a GPU):
+//   1MN  gemm_sp_kernel with wave tile (MT, NT) = (M, N): 135 = 192 x 320, 134 = 192 x 256, 124 = 128 x 256, 144 = 256 x 256 GEGLU;
+//        +1000 when it runs on swapped operands (transposed output)
+//   210 / 220 / 230  wsgemm_kernel K = 320 / K = 640 / GEGLU
+//   301 / 302 / 303  gemm_kernel 64-column tiles / 256 x 128 / 128 x 128
+template <bool CONV, bool GEGLU, bool DRY>
+static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const int force_nt, const int ncu) {
   // Dispatch table, from same-box A/B runs on MI355X (profiles/r0*_ab_*.log).  One knob survives, used by the
   // parity tests: MD_GEMM_SP = 0 off | 1 every eligible problem | 2 automatic (default).  (The two-waves-per-SIMD ping-pong
   // kernels of rounds 1-2, gemm_pp.h, lost every shape they used to win to gemm_sp_kernel and were removed in round 3.)
-  static const int sp = env_int("MD_GEMM_SP", 2);
   // gemm_sp_kernel's tile: 256 x 256 for GEGLU; 192 x 320, 192 x 256 or 128 x 256 otherwise, whichever needs least time by the model
   // rounds x (T0 + K tiles x t_k): rounds = ceil(tiles / CUs) of the persistent grid, T0 ~ 4 us per output tile outside its K loop,
   // t_k = 1.56 / 1.28 / 0.95 us per 64-deep K tile (15 / 12 / 8 MFMAs per k-step; profiles/r03_ab_gemm_sp_tiles.log).
@@ -623,26 +627,24 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
       GemmParams q = p;
       q.A = p.W; q.W = p.A; q.lda = p.K; q.M = p.N; q.N = p.M; q.transpose_out = 0; q.bias_rows = 1;
       if (sp_eligible<false, false, 4>(q)) {
-        const int ncu = md_device_cus();
         auto cost = [&](int bm, double tk) {
           const long tiles = (long)cdiv(q.M, bm) * (q.N / 256);
           return (double)cdiv(tiles, ncu) * (4.0 + (q.K / 64) * tk);
         };
-        static const int force_nt_t = env_int("MD_GEMM_SP_NT", 0);
-        const bool small = force_nt_t == 2 || (force_nt_t != 4 && cost(128, 0.95) < cost(192, 1.28));
+        const bool small = force_nt == 2 || (force_nt != 4 && cost(128, 0.95) < cost(192, 1.28));
         const long tiles = (long)cdiv(q.M, small ? 128 : 192) * (q.N / 256);
         if (sp == 1 || (tiles >= 112 && q.K >= 256)) {
-          if (small) launch_sp<false, false, 4, 2>(q, stream);
-          else launch_sp<false, false, 4>(q, stream);
-          return;
+          if constexpr (!DRY) {
+            if (small) launch_sp<false, false, 4, 2>(q, stream);
+            else launch_sp<false, false, 4>(q, stream);
+          }
+          return small ? 1124 : 1134;
         }
       }
     }
   }
-  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 pin 192 x 320 / 192 x 256 / 128 x 256
   int nt = GEGLU ? 4 : 0;                                         // 5, 4: 192-row tiles; 2: 128 x 256
   if constexpr (!GEGLU) {
-    const int ncu = md_device_cus();
     auto cost = [&](int bm, int bn, double tk) {
       const long tiles = (long)cdiv(p.M, bm) * (p.N / bn);
       return (double)cdiv(tiles, ncu) * (4.0 + (p.K / 64) * tk);
@@ -656,27 +658,29 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
     nt = 0;
   }
   auto run_sp = [&]() {
-    if constexpr (GEGLU) launch_sp<CONV, true>(p, stream);
-    else if (nt == 4) launch_sp<CONV, false, 4>(p, stream);
-    else if (nt == 2) launch_sp<CONV, false, 4, 2>(p, stream);
-    else launch_sp<CONV, false, 5>(p, stream);
+    if constexpr (!DRY) {
+      if constexpr (GEGLU) launch_sp<CONV, true>(p, stream);
+      else if (nt == 4) launch_sp<CONV, false, 4>(p, stream);
+      else if (nt == 2) launch_sp<CONV, false, 4, 2>(p, stream);
+      else launch_sp<CONV, false, 5>(p, stream);
+    }
+    return GEGLU ? 144 : (nt == 4 ? 134 : (nt == 2 ? 124 : 135));
   };
-  if (sp == 1 && nt) {
-    run_sp();
-    return;
-  }
+  if (sp == 1 && nt) return run_sp();
   // 1. HBM-bound short-K projections on long token matrices: W-stationary streaming kernel (gemm_ws.h), plain and GEGLU (K = 320)
   if constexpr (!CONV && !GEGLU) {
     if (ws_eligible(p)) {
-      if (p.K == 320) launch_ws<10, 5>(p, stream);
-      else launch_ws<20, 2>(p, stream);
-      return;
+      if constexpr (!DRY) {
+        if (p.K == 320) launch_ws<10, 5>(p, stream);
+        else launch_ws<20, 2>(p, stream);
+      }
+      return p.K == 320 ? 210 : 220;
     }
   }
   if constexpr (!CONV && GEGLU) {
     if (ws_geglu_eligible(p)) {
-      launch_ws_geglu(p, stream);
-      return;
+      if constexpr (!DRY) launch_ws_geglu(p, stream);
+      return 230;
     }
   }
   // 2. one-wave-per-SIMD flavour (gemm_sp.h), same-box table in profiles/r03_ab_gemm_sp_tiles.log: every 3x3 conv and every plain
@@ -686,17 +690,16 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   if (sp > 0 && nt) {
     const long tiles = (long)cdiv(p.M, GEGLU ? 256 : (nt == 2 ? 128 : 192)) * (p.N / (nt == 5 ? 320 : 256));
     const bool pick = GEGLU ? p.K >= 640 : (tiles >= 112 && (CONV || p.K >= 640));
-    if (pick) {
-      run_sp();
-      return;
-    }
+    if (pick) return run_sp();
   }
   // 3. the occupancy flavours of gemm_kernel
   if constexpr (!GEGLU) {
     if (p.N <= 64) {                                              // 64-column tiles: conv_out (N = 4), MAN's first conv
-      if (CONV) launch_variant<CONV, false, 1, 64, 2>(p, stream);
-      else launch_variant<CONV, false, 1, 64, 1, 2, 3>(p, stream);
-      return;
+      if constexpr (!DRY) {
+        if (CONV) launch_variant<CONV, false, 1, 64, 2>(p, stream);
+        else launch_variant<CONV, false, 1, 64, 1, 2, 3>(p, stream);
+      }
+      return 301;
     }
   }
   // 256x128 tile, 4 waves x (128x64 per wave = 4x2 MFMA tiles, 8 independent accumulators), single 48-KiB stage, 2
@@ -705,13 +708,24 @@ static void launch_any(GemmParams& p, hipStream_t stream) {
   // and on the 24x24 / 12x12 convs (too few tiles to fill 256 CUs twice); plain Linear GEMMs only with a deep K loop
   const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
   if (tiles256 >= 1024 && (CONV || GEGLU || p.K >= 2048)) {
-    launch_variant<CONV, GEGLU, 2, 64, 1, 2, 2, 4>(p, stream);
-    return;
+    if constexpr (!DRY) launch_variant<CONV, GEGLU, 2, 64, 1, 2, 2, 4>(p, stream);
+    return 302;
   }
   // 128x128: Linear GEMMs single 32-KiB stage at 3 workgroups/CU (occupancy hides the DMA latency), 3x3 convs a 2-deep ring
-  if (CONV) launch_variant<CONV, GEGLU, 2, 64, 2>(p, stream);
-  else launch_variant<CONV, GEGLU, 2, 64, 1, 2, 3>(p, stream);
+  if constexpr (!DRY) {
+    if (CONV) launch_variant<CONV, GEGLU, 2, 64, 2>(p, stream);
+    else launch_variant<CONV, GEGLU, 2, 64, 1, 2, 3>(p, stream);
+  }
+  return 303;
 }
+
+template <bool CONV, bool GEGLU>
+static void launch_any(GemmParams& p, hipStream_t stream) {
+  static const int sp = env_int("MD_GEMM_SP", 2);
+  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 pin 192 x 320 / 192 x 256 / 128 x 256
+  dispatch_any<CONV, GEGLU, false>(p, stream, sp, force_nt, md_device_cus());
+}
+
 
 static int launch_gemm(GemmParams& p, bool conv, hipStream_t stream) {
   MD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "md_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -794,4 +808,34 @@ extern "C" int md_conv3x3_pad_nhwc_f16(const void* X, const void* W, void* Y, in
                                        int stride, int upsample, int pad_lo, const void* bias, const void* residual, int ldr,
                                        const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
   return conv3x3_common(X, W, Y, ldy, B, Hin, Win, Cin, Cout, stride, upsample, pad_lo, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dispatch queries
+// Which kernel the AUTOMATIC dispatch (MD_GEMM_SP = 2, no pinned tile) picks for a problem on a chip with `ncu` compute units; nothing
+// is launched and no device is touched, so the table is pinned by CPU tests (tests/test_host_cpu.py).  epi: bit 0 residual, bit 1
+// row-broadcast operand, bit 2 bias.  Operands are taken as 16-byte aligned with dense rows (lda = K, ldc = N or M).
+static const half_t* plan_ptr(int which) { return reinterpret_cast<const half_t*>((uintptr_t)0x100000 * (which + 1)); }
+
+extern "C" int md_gemm_plan(int M, int N, int K, int act, int transpose_out, int epi, int ncu) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 64 || ncu <= 0) return MD_ERR_ARG;
+  GemmParams p = {};
+  p.A = plan_ptr(0); p.W = plan_ptr(1); p.C = const_cast<half_t*>(plan_ptr(2));
+  p.residual = (epi & 1) ? plan_ptr(3) : nullptr; p.rowadd = (epi & 2) ? plan_ptr(4) : nullptr; p.bias = (epi & 4) ? plan_ptr(5) : nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = transpose_out ? M : (act == ACT_GEGLU ? N / 2 : N); p.ldr = N; p.ldra = N;
+  p.rows_per_group = M; p.act = act; p.transpose_out = transpose_out;
+  if (act == ACT_GEGLU) return dispatch_any<false, true, true>(p, nullptr, 2, 0, ncu);
+  return dispatch_any<false, false, true>(p, nullptr, 2, 0, ncu);
+}
+
+extern "C" int md_conv3x3_plan(int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int epi, int ncu) {
+  if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cin % 64 || Cout <= 0 || ncu <= 0 || (stride != 1 && stride != 2) || (upsample && stride != 1)) return MD_ERR_ARG;
+  GemmParams p = {};
+  p.A = plan_ptr(0); p.W = plan_ptr(1); p.C = const_cast<half_t*>(plan_ptr(2));
+  p.residual = (epi & 1) ? plan_ptr(3) : nullptr; p.rowadd = (epi & 2) ? plan_ptr(4) : nullptr; p.bias = (epi & 4) ? plan_ptr(5) : nullptr;
+  p.ldc = Cout; p.ldr = Cout; p.ldra = Cout; p.lda = Cin;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample; p.pad = 1;
+  p.Hout = ((Hin << upsample) + 2 - 3) / stride + 1;
+  p.Wout = ((Win << upsample) + 2 - 3) / stride + 1;
+  p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.rows_per_group = p.Hout * p.Wout; p.act = ACT_NONE;
+  return dispatch_any<true, false, true>(p, nullptr, 2, 0, ncu);
 }

@@ -161,3 +161,45 @@ def test_clip_tower_key_layout_and_preprocess_match_transformers(golden_dir):
     assert tuple(M.clip_preprocess(img.resize((300, 260))).shape) == (1, 3, 224, 224)
     with pytest.raises(NotImplementedError):
         M.CLIPVisionModelWithProjection(dict(meta["config"], hidden_act="gelu"))
+
+
+def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
+    """The automatic kernel choice for every MFMA-bound launch shape of configs[1] (768 x 768, 16 frames, CFG: 32-frame batches), as
+    measured best on MI355X in same-box A/B runs (profiles/r03_ab_gemm_sp_tiles.log, r03_ab_gemm_sp_tile_128x256.log,
+    r03_ab_transposed_sp.log).  md_gemm_plan / md_conv3x3_plan run the launcher's own decision code without
+    touching a device: 135 / 134 / 124 = gemm_sp_kernel 192x320 / 192x256 / 128x256, 144 = its 256x256 GEGLU flavour, +1000 on
+    swapped operands (transposed output), 210 / 220 / 230 = W-stationary streaming kernel, 301 / 303 = multi-workgroup kernel."""
+    from mikudance_amd import _lib, ops
+    lib = _lib.load()
+    ncu, G = 256, ops.ACT_GEGLU
+    gemm = {
+        # level 0 (96 x 96): HBM-bound projections and the K = 320 GEGLU stream; FF-out on the big tile
+        (294912, 320, 320, 0, 0, 5): 210, (294912, 960, 320, 0, 0, 0): 210, (294912, 2560, 320, G, 0, 4): 230, (294912, 320, 1280, 0, 0, 5): 135,
+        # level 1 (48 x 48)
+        (73728, 640, 640, 0, 0, 5): 220, (73728, 5120, 640, G, 0, 4): 144, (73728, 640, 2560, 0, 0, 5): 135,
+        # level 2 (24 x 24): N = 1280 takes the 192 x 256 tile (480 tiles = 1.9 rounds instead of 384 = 1.5)
+        (18432, 1280, 1280, 0, 0, 5): 134, (18432, 10240, 1280, G, 0, 4): 144, (18432, 1280, 5120, 0, 0, 5): 134, (18432, 3840, 1280, 0, 0, 0): 135,
+        (18432, 2560, 1280, 0, 0, 0): 135,
+        # level 3 (12 x 12): 128 x 256 tiles fill more CUs
+        (4608, 1280, 1280, 0, 0, 5): 124, (4608, 10240, 1280, G, 0, 4): 144, (4608, 1280, 5120, 0, 0, 5): 124, (4608, 2560, 1280, 0, 0, 0): 134,
+        # V^T projections (transposed output): swapped operands
+        (294912, 320, 320, 0, 1, 0): 1134, (73728, 640, 640, 0, 1, 0): 1124, (18432, 1280, 1280, 0, 1, 0): 1134, (4608, 1280, 1280, 0, 1, 0): 1124,
+        # not sp: ragged / tiny N, few tiles
+        (257 * 32, 768, 320, 0, 0, 4): 303, (294912, 4, 320, 0, 0, 4): 301, (2048, 320, 1280, 0, 0, 4): 303,
+    }
+    for args, want in gemm.items():
+        assert lib.md_gemm_plan(*args, ncu) == want, (args, lib.md_gemm_plan(*args, ncu), want)
+    conv = {  # (B, H = W, Cin, Cout, stride, upsample)
+        (32, 96, 320, 320, 1, 0): 135, (32, 96, 640, 320, 1, 0): 135, (32, 96, 960, 320, 1, 0): 135, (32, 48, 640, 640, 1, 0): 135,
+        (32, 48, 1920, 640, 1, 0): 135, (32, 24, 1280, 1280, 1, 0): 134, (32, 24, 2560, 1280, 1, 0): 134, (32, 12, 1280, 1280, 1, 0): 124,
+        (32, 12, 2560, 1280, 1, 0): 124, (32, 48, 640, 640, 1, 1): 135, (32, 24, 1280, 1280, 1, 1): 135, (32, 12, 1280, 1280, 1, 1): 134,
+        (32, 96, 320, 320, 2, 0): 135, (32, 48, 640, 640, 2, 0): 135, (32, 24, 1280, 1280, 2, 0): 124, (32, 96, 320, 4, 1, 0): 301,
+        (2, 8, 64, 320, 1, 0): 303,
+    }
+    for (B, H, cin, cout, st, up), want in conv.items():
+        got = lib.md_conv3x3_plan(B, H, H, cin, cout, st, up, 4, ncu)
+        assert got == want, ((B, H, cin, cout, st, up), got, want)
+    # argument errors are reported, not guessed around
+    assert lib.md_gemm_plan(128, 320, 100, 0, 0, 0, ncu) < 0 and lib.md_conv3x3_plan(1, 8, 8, 60, 320, 1, 0, 0, ncu) < 0
+    # a smaller chip changes the rounds, hence the tile: the model is per device
+    assert lib.md_gemm_plan(18432, 1280, 1280, 0, 0, 5, 192) in (134, 135, 124)
