@@ -719,10 +719,40 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
   return 303;
 }
 
+// gemm_sp_kernel addresses A through a buffer descriptor with 32-bit byte offsets (< 2^31).  A token matrix beyond that (configs[4]:
+// 983 040 tokens x 1280 channels = 2.5 GB) is cut into row blocks that each fit: same kernels, same results (rows are independent).
+// Returns the number of row blocks (1 = no split) for a plain GEMM that the sp kernel would otherwise have to turn down.
+static int sp_row_blocks(const GemmParams& p, int* rows_per_block) {
+  const unsigned long long a_bytes = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2, lim = 1ull << 31;
+  *rows_per_block = p.M;
+  if (a_bytes < lim || p.transpose_out || p.rowadd || p.K < 640) return 1;
+  int rows = (int)((lim - (unsigned long long)p.K * 2) / ((unsigned long long)p.lda * 2));
+  rows -= rows % 3840;                             // whole tiles of every sp shape (192, 128, 256 rows) and of the 16-row streams
+  if (rows <= 0) return 1;
+  *rows_per_block = rows;
+  return cdiv(p.M, rows);
+}
+
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
   static const int sp = env_int("MD_GEMM_SP", 2);
   static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 pin 192 x 320 / 192 x 256 / 128 x 256
+  if constexpr (!CONV) {
+    int rows;
+    const int nb = sp > 0 ? sp_row_blocks(p, &rows) : 1;
+    if (nb > 1) {
+      for (int b = 0; b < nb; ++b) {
+        GemmParams c = p;
+        const size_t off = (size_t)b * rows;
+        c.A = p.A + off * p.lda;
+        c.C = p.C + off * p.ldc;
+        if (p.residual) c.residual = p.residual + off * p.ldr;
+        c.M = b + 1 < nb ? rows : p.M - (int)off;
+        dispatch_any<false, GEGLU, false>(c, stream, sp, force_nt, md_device_cus());
+      }
+      return;
+    }
+  }
   dispatch_any<CONV, GEGLU, false>(p, stream, sp, force_nt, md_device_cus());
 }
 
@@ -823,6 +853,8 @@ extern "C" int md_gemm_plan(int M, int N, int K, int act, int transpose_out, int
   p.residual = (epi & 1) ? plan_ptr(3) : nullptr; p.rowadd = (epi & 2) ? plan_ptr(4) : nullptr; p.bias = (epi & 4) ? plan_ptr(5) : nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = transpose_out ? M : (act == ACT_GEGLU ? N / 2 : N); p.ldr = N; p.ldra = N;
   p.rows_per_group = M; p.act = act; p.transpose_out = transpose_out;
+  int rows;
+  if (sp_row_blocks(p, &rows) > 1) p.M = rows;                   // a token matrix beyond 2^31 bytes runs in row blocks: plan of a block
   if (act == ACT_GEGLU) return dispatch_any<false, true, true>(p, nullptr, 2, 0, ncu);
   return dispatch_any<false, false, true>(p, nullptr, 2, 0, ncu);
 }

@@ -450,6 +450,21 @@ def test_streaming_gemms_at_config5_token_count(dev):
         del hg
 
 
+def test_wide_k_gemm_at_config5_token_count_runs_in_row_blocks(dev):
+    """M = 983 040 tokens x K = 1280 (the level-0 FeedForward output projection of configs[4]): A is 2.5 GB, beyond the 2^31-byte reach of
+    gemm_sp_kernel's buffer descriptor, so the launcher cuts it into row blocks (gemm.hip sp_row_blocks); every element against fp32,
+    in place on the residual like the transformer block calls it."""
+    M, N, K = 983040, 320, 1280
+    a = _drnd(dev, M, K, seed=11)
+    w, b, res = _drnd(dev, N, K, seed=12, scale=K ** -0.5), _drnd(dev, N, seed=13), _drnd(dev, M, N, seed=14)
+    hs = res.clone()
+    ops.gemm(a, w, bias=b, residual=hs, out=hs)
+    for r0 in range(0, M, 245760):
+        ref = a[r0:r0 + 245760].float() @ w.float().t() + b.float() + res[r0:r0 + 245760].float()
+        _close_dev(hs[r0:r0 + 245760], ref, what=f"row-blocked gemm rows {r0}")
+        del ref
+
+
 def test_attention_at_config5_sequence_length(dev):
     """Lq = Lk = 16 384 (128 x 128 latents, d = 40): 256 key tiles."""
     B, H, D, L = 1, 8, 40, 16384
