@@ -1,6 +1,5 @@
 """CPU: host logic of the AutoencoderKL port (key layout, legacy checkpoint names, loader); no kernels are called."""
 import json
-import os
 
 import pytest
 import torch

@@ -1,12 +1,11 @@
 """Kernel micro-benchmarks at the config-2 shapes (HIP events, 10 iterations after 3 warm-ups).  Debug/tuning tool."""
-import json
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mikudance_amd import ops, packing  # noqa: E402
+from mikudance_amd import ops  # noqa: E402
 
 dev = torch.device("cuda")
 
