@@ -201,5 +201,8 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
         assert got == want, ((B, H, cin, cout, st, up), got, want)
     # argument errors are reported, not guessed around
     assert lib.md_gemm_plan(128, 320, 100, 0, 0, 0, ncu) < 0 and lib.md_conv3x3_plan(1, 8, 8, 60, 320, 1, 0, 0, ncu) < 0
+    # configs[4]: 983 040 tokens.  K = 1280 makes A 2.5 GB, beyond the sp kernel's 2^31-byte reach: planned (and launched) in row blocks
+    assert lib.md_gemm_plan(983040, 320, 1280, 0, 0, 5, ncu) == 135 and lib.md_gemm_plan(983040, 320, 320, 0, 0, 5, ncu) == 210
+    assert lib.md_conv3x3_plan(60, 128, 128, 960, 320, 1, 0, 4, ncu) == 135
     # a smaller chip changes the rounds, hence the tile: the model is per device
     assert lib.md_gemm_plan(18432, 1280, 1280, 0, 0, 5, 192) in (134, 135, 124)
