@@ -7,8 +7,9 @@
 A "step" is one pass of the hot path over one batch of synthetic input: the full denoising loop (20 DDIM steps,
 reference_unet + denoising_unet + motion modules + CFG + DDIM) of ONE 768x768x16-frame clip per GPU (BASELINE.json
 configs[1]; weak scaling: every added GPU brings its own clip, configs[3]).  Inputs are resident in HBM when the timed
-region starts (rank 0 scatters the per-clip conditioning over RCCL inside the region when N > 1, and gathers the final
-latents).  value = frames of all ranks / max-over-ranks time.
+region starts: every rank stages its own clip (--scatter: rank 0 owns the batch and scatters the per-clip conditioning over
+RCCL inside the region); the final latents are gathered on rank 0 inside the region.  value = frames of all ranks /
+max-over-ranks time.
 
 Extra objects on the JSON line:
   roofline     dominant kernel: algorithmic FLOPs per launch / average launch duration measured live with HIP events on the
@@ -16,8 +17,8 @@ Extra objects on the JSON line:
                pass of the same clip run right after the timed region (instrumenting ~17k launches per clip inside the timed
                region would add its own launch gaps to `value`; both times are reported)
   cpu_baseline the CPU oracle (a port of the reference's PyTorch path, oracle/cpu_ref.py) timed on this host's cores on a
-               bounded sample after a warm-up: configs[0] in full (4 steps) and ONE DDIM step of 2 frames at 768x768 with the
-               full-width UNets, literal reference algorithm
+               bounded sample after a warm-up: configs[0] in full (4 steps) and ONE DDIM step of one frame at 768x768 with the
+               full-width UNets, literal reference algorithm, each on the best intra-op thread count of a sweep
 """
 import argparse
 import json
@@ -48,6 +49,10 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the AutoencoderKL timing behind the extra keys vae_ms_per_clip / e2e_frames_per_s")
     ap.add_argument("--no-reuse", action="store_true", help="literal reference algorithm: reference UNet at every step on 2f frames")
     ap.add_argument("--small", action="store_true", help="reduced-width UNets (debug only; NOT the benchmark)")
+    ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 owns the batch and scatters the per-clip conditioning inside "
+                    "the timed region (default: every rank stages its own clip before it)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="plumbing test only (tests/test_bench_contract_cpu.py): CPU + gloo, the "
+                    "kernels replaced by a stand-in; the line says so and carries no roofline")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
                     help="BASELINE.json configs[i]: 1 = 768x768x16f/20 steps (the headline, default); 2 = the same shapes with full "
                          "guidance (scene-motion flow from real camera tracks through camera_to_scene_motion + non-zero face/hand "
@@ -61,24 +66,39 @@ def main():
     from mikudance_amd.synth import synth_inputs
 
     rank, world = dp.init()
+    try:
+        _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipeline, SCHED_KWARGS, build_models, synth_inputs)
+    finally:
+        dp.shutdown()                                        # every rank, also on an exception: no rank is left inside a collective
+
+
+def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipeline, SCHED_KWARGS, build_models, synth_inputs):
     if world > 1:
         # N ranks share the host: cap the intra-op pool (weight synthesis, packing) so that 8 ranks do not spin 8 x 128 threads
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
-    _lib.load()
+    dry = args.dry_run_cpu
+    if dry:
+        assert args.small, "--dry-run-cpu is the plumbing test (reduced width, no compute): never a measurement"
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        _lib.load()
+    sync = (lambda: None) if dry else torch.cuda.synchronize
 
     geom = None if args.small else FULL
     ctx = (5, 64) if args.small else (257, 768)
     t0 = time.time()
-    want_cpu = world == 1 and not args.no_cpu_baseline
+    want_cpu = world == 1 and not args.no_cpu_baseline and not dry
     ref, den, ref_sd, den_sd = build_models(geom=geom, device=dev, keep_state_dicts=want_cpu)
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     pipe.reference_reuse = not args.no_reuse
     h = w = args.size // 8
     setup_s = time.time() - t0
+    # the plumbing test (CPU, gloo) replaces the kernels by a stand-in: launch, collectives, timing protocol and the JSON line
+    denoise = (lambda lat, rl, emb, steps, g: lat * 0.5) if dry else pipe.denoise
 
     def make_clip(seed):
         lat, rl, emb = synth_inputs(args.frames, h, w, ctx_len=ctx[0], ctx_dim=ctx[1], seed=seed)
@@ -86,49 +106,63 @@ def main():
             rl = full_guidance(rl, args.frames, h, w)
         return lat.half(), rl.half(), emb.half()
 
-    def one_step(step_idx):
-        # rank 0 owns the batch: scatter the per-clip conditioning, every rank denoises its clip, gather the latents
-        clips = [tuple(t.to(dev) for t in make_clip(100 + r)) for r in range(world)] if rank == 0 else None
-        return clips
-
-    # inputs resident in HBM before the timed region
-    staged = one_step(0)
+    # Inputs resident in HBM before the timed region.  Default: every rank stages ITS OWN clip (clip i = seed 100 + i lives on
+    # rank i: the conditioning of a clip is produced by the VAE / CLIP of the rank that denoises it), so the timed region holds
+    # the denoising loop and ONE gather of the final latents.  --scatter: rank 0 owns the whole batch (BASELINE configs[3] as a
+    # service front-end would see it) and the timed region adds ONE scatter of the per-clip conditioning (~8.5 MB per clip).
+    if args.scatter:
+        staged = [tuple(t.to(dev) for t in make_clip(100 + r)) for r in range(world)] if rank == 0 else None
+    else:
+        staged = tuple(t.to(dev) for t in make_clip(100 + rank))
 
     def run(clips):
-        lat, rl, emb = dp.scatter_clips(clips, dev)
-        out = pipe.denoise(lat, rl, emb, args.ddim_steps, args.guidance)
+        lat, rl, emb = dp.scatter_clips(clips, dev) if args.scatter else clips
+        out = denoise(lat, rl, emb, args.ddim_steps, args.guidance)
         return dp.gather_latents(out)
 
     for _ in range(args.warmup):
         res = run(staged)
-    torch.cuda.synchronize()
+    sync()
     dp.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = run(staged)
-    torch.cuda.synchronize()
+    sync()
     dp.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(elapsed, dev)
+    n_ranks_seen = int(round(dp.sum_over_ranks(1.0, dev)))          # every rank of the job reached the end of the timed region
 
     # Per-launch HIP-event instrumentation (roofline, kernel families, executed FLOPs) runs on ONE extra pass of the same
-    # clip right after the timed region: two event records per launch x ~17k launches per clip add launch gaps that would
-    # otherwise be charged to `value` (measured: see "instrumented_ms_per_step" next to "ms_per_step").
+    # clip right after the timed region, on rank 0 only and without collectives: two event records per launch x ~17k launches
+    # per clip add launch gaps that would otherwise be charged to `value` (see "instrumented_ms_per_step" next to "ms_per_step").
     inst_steps = 1
-    _lib.PROFILER.start()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(inst_steps):
-        res = run(staged)
-    torch.cuda.synchronize()
-    inst_elapsed = time.perf_counter() - t1
-    _lib.PROFILER.stop()
+    inst_elapsed = 0.0
+    if rank == 0 and not dry:
+        clip0 = staged[0] if args.scatter else staged
+        _lib.PROFILER.start()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(inst_steps):
+            pipe.denoise(*clip0, args.ddim_steps, args.guidance)
+        sync()
+        inst_elapsed = time.perf_counter() - t1
+        _lib.PROFILER.stop()
     dp.barrier()
 
     if rank != 0:
         return
-    assert all(torch.isfinite(r.float()).all() for r in res), "non-finite latents"
+    assert len(res) == world and all(torch.isfinite(r.float()).all() for r in res), "missing or non-finite latents"
+    if dry:
+        # plumbing line of the CPU test: same launch / collective / timing protocol, no kernels -> no throughput claim
+        print(json.dumps({"metric": f"frames/sec ({args.size}x{args.size}, {args.frames}f, {args.ddim_steps} DDIM steps)", "value": None,
+                          "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f16", "data": "dry-run (CPU + gloo plumbing test: kernels replaced by a stand-in, NOT a measurement)",
+                          "config": {"workload": "dry-run", "parallelism": f"dp{world}", "input_staging": "scatter" if args.scatter else "rank-local"},
+                          "clips_gathered": len(res), "clip_means": [float(r.float().mean()) for r in res]}))
+        return
     prof = _lib.PROFILER.summary()
     total_flops = sum(d["flops"] for d in prof.values()) / inst_steps
     kernel_ms = sum(d["ms"] for d in prof.values()) / inst_steps
@@ -169,13 +203,14 @@ def main():
     line = {
         "metric": f"frames/sec ({args.size}x{args.size}, {args.frames}f, {args.ddim_steps} DDIM steps)", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "n_ranks_seen": n_ranks_seen,
         "config": {"workload": f"configs[{args.config}]: {args.size}x{args.size}, {args.frames}-frame clip, {args.ddim_steps} DDIM steps, fp16, "
                                "reference_unet + denoising_unet + motion_module, CFG 3.5, one clip per GPU per step"
                                + (", full guidance: scene-motion flow from the demo camera tracks (tests/golden/g2) through "
                                   "camera_to_scene_motion + non-zero face/hand latents" if args.config == 2 else "")
                                + (", context 30 / overlap 8 -> 3 wrapping windows, 60-frame UNet batches" if args.config == 4 else ""),
-                   "parallelism": f"dp{world}", "reference_reuse": pipe.reference_reuse, "weights": "random-init SD-1.5 geometry "
+                   "parallelism": f"dp{world}", "input_staging": "scatter from rank 0 inside the timed region" if args.scatter
+                   else "rank-local (every rank stages its own clip in HBM before the timed region)", "reference_reuse": pipe.reference_reuse, "weights": "random-init SD-1.5 geometry "
                    "(N(0,1/fan_in), seeds 1234/4321)", "width": "reduced(debug)" if args.small else "full"},
         "executed_tflop_per_clip": total_flops / 1e12, "mfma_frac_whole_loop": total_flops / (elapsed / args.steps) / PEAK_MFMA_F16,
         "peak_hbm_gb": peak_gb, "kernel_ms_per_clip": kernel_ms, "instrumented_ms_per_step": inst_elapsed / inst_steps * 1e3, "setup_s": setup_s,
@@ -232,8 +267,10 @@ def full_guidance(ref_latents, frames, h, w):
 
 
 def vae_ms_per_clip(dev, size, frames, batch=8):
-    """AutoencoderKL (sd-vae-ft-mse geometry, seeded random weights) at the benchmark size: F decodes + 3F + 2 encodes, timed once
-    after a warm-up pass.  Not part of `value` (the metric is the denoising loop)."""
+    """AutoencoderKL (sd-vae-ft-mse geometry, seeded random weights) at the benchmark size: F decodes + 3F + 2 encodes in batches of
+    8 images, median of three wall-clock passes after a warm-up pass.  Images and latents are device-resident when a pass starts
+    (like `value`: the product's _encode_many additionally copies each 8-image batch host -> device, 9.4 MB per image, which is
+    NOT in this figure).  Not part of `value` (the metric is the denoising loop)."""
     from mikudance_amd import AutoencoderKL
     from mikudance_amd.synth import synth_state_dict
     vae = AutoencoderKL()
@@ -248,25 +285,28 @@ def vae_ms_per_clip(dev, size, frames, batch=8):
             vae.decode(lat[i:i + batch]).sample
         for i in range(0, imgs.shape[0], batch):
             vae.encode(imgs[i:i + batch]).latent_dist.mean
+    times = []
     with torch.no_grad():
-        once()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        once()
-        torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3
+        once()                                                           # warm-up: allocator growth, packed weights
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            once()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+    return sorted(times)[1]                                              # median of three
 
 
 def cpu_baseline(ref_sd, den_sd, args, ctx):
     """The CPU oracle (a port of the reference's PyTorch path: the same ATen ops, fp32) on this host's cores, on a bounded
     sample, after one untimed warm-up pass (thread pool, allocator, oneDNN primitive caches):
       (1) BASELINE configs[0] IN FULL: 256x256 (32x32 latents), 4 frames, 4 DDIM steps, CFG, literal reference algorithm;
-      (2) ONE DDIM step at the benchmark resolution on f = 2 frames (reference_unet + denoising_unet on the [uncond | cond]
-          pair with temporal attention over the 2 frames) -- `value` = 2 frames / (ddim_steps x that time), i.e. the step
-          time extrapolated linearly over the steps; a full 16-frame clip is ~2 PFLOP = hours of CPU.
-    configs[0] runs on the best intra-op thread count of a sweep over 8 / 16 / 32 / 64 / all threads on one of its steps
-    (`config1_cores`, `thread_sweep_s_per_step`); the 768x768 step behind `value` uses all threads (`cores`); the physical core
-    count of the host is reported beside them."""
+      (2) ONE DDIM step at the benchmark resolution on ONE frame (reference_unet + denoising_unet on the [uncond | cond]
+          pair) -- `value` = 1 frame / (ddim_steps x that time), i.e. the frame-step time extrapolated linearly over frames and
+          steps; a full 16-frame clip is ~2 PFLOP = hours of CPU.
+    Both legs run on the BEST intra-op thread count of a sweep (configs[0]: 8 / 16 / 32 / 64 / all on one of its steps ->
+    `config1_cores`, `thread_sweep_s_per_step`; the 768x768 step: 16 / 32 / 64 / all -> `cores`, `thread_sweep_s_per_step_at_size`);
+    the physical core count of the host is reported beside them."""
     from oracle import cpu_ref as O                                     # cpu_baseline leg only
     from mikudance_amd.synth import synth_inputs
     try:
@@ -292,22 +332,32 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
         t0 = time.perf_counter()
         O.denoise_loop(ref_sd, den_sd, lat1, rl1, emb1, 4, guidance_scale=args.guidance)
         dt1 = time.perf_counter() - t0
-        # the 768x768 step is made of large convolutions / GEMMs that do use every core: all threads (the sweep above is about
-        # the small operators of configs[0])
-        torch.set_num_threads(avail)
+        # The step at the benchmark resolution: ONE frame (the per-frame cost of both UNets is linear in the frame count; the
+        # f x f temporal core is ~0.1 % of the FLOPs), one untimed warm-up step, then one timed step per intra-op thread count
+        # of the sweep -- `value` is the BEST of them, `cores` the count that achieved it.
         h = w = args.size // 8
-        f = 2
+        f = 1
         lat, rl, emb = synth_inputs(f, h, w, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100)
-        t0 = time.perf_counter()
-        O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
-        dt2 = time.perf_counter() - t0
-    return {"value": f / (dt2 * args.ddim_steps), "unit": "frames/s", "cores": avail, "physical_cores": physical, "kind": "port",
+        torch.set_num_threads(avail)
+        O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)             # warm-up (untimed)
+        sweep2 = {}
+        for n in sorted({n for n in (16, 32, 64, avail) if n <= avail}, reverse=True):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
+            sweep2[n] = time.perf_counter() - t0
+        best = min(sweep2, key=sweep2.get)
+        dt2 = sweep2[best]
+        torch.set_num_threads(avail)
+    return {"value": f / (dt2 * args.ddim_steps), "unit": "frames/s", "cores": best, "physical_cores": physical, "kind": "port",
+            "thread_sweep_s_per_step_at_size": {str(k): round(v, 2) for k, v in sorted(sweep2.items())},
             "config1_cores": threads, "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
             "config1_full_s": dt1, "config1_frames_per_s": 4.0 / dt1,
-            "sample": f"after one warm-up pass: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) on {threads} intra-op threads "
-                      f"(best of the sweep) = {dt1:.1f} s; "
-                      f"(2) 1 DDIM step of {f} frames at {args.size}x{args.size} (reference_unet + denoising_unet, CFG pair, fp32, full-width "
-                      f"random-init weights) on {avail} threads = {dt2:.1f} s; value = {f} frames / ({args.ddim_steps} steps x {dt2:.1f} s)"}
+            "sample": f"after one warm-up pass each: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) on {threads} "
+                      f"intra-op threads (best of the sweep) = {dt1:.1f} s; (2) 1 DDIM step of {f} frame at {args.size}x{args.size} (reference_unet + "
+                      f"denoising_unet, CFG pair, fp32, full-width random-init weights, literal algorithm) timed on "
+                      f"{'/'.join(str(k) for k in sorted(sweep2))} threads, best = {best} threads = {dt2:.1f} s; value = {f} frame / "
+                      f"({args.ddim_steps} steps x {dt2:.1f} s): one frame-step extrapolated linearly over frames and steps"}
 
 
 if __name__ == "__main__":

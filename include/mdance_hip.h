@@ -119,6 +119,13 @@ int md_window_accumulate(const void* pred, void* noise_sum, void* counter, const
 int md_cfg_ddim_step(void* latents, const void* noise_sum, const void* counter, int Ftot, int HW, int halves,
                      float guidance, float alpha_t, float alpha_prev, void* stream);
 
+/* The same step for eta > 0 (DDIM's stochastic variant; `eta` of MikuDanceVideoPipeline.__call__,
+ * src/pipelines/pipeline_mikudance.py:152-171,375 -> scheduler.step(..., eta=, generator=)): sigma_t = eta * sqrt((1 - a_prev) /
+ * (1 - a_t) * (1 - a_t / a_prev)), prev = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma_t^2) eps + sigma_t z with z = variance_noise,
+ * fp16, laid out like the latents (Ftot, HW, 4) -- the caller draws it from ITS generator (diffusers randn_tensor). */
+int md_cfg_ddim_step_eta(void* latents, const void* noise_sum, const void* counter, const void* variance_noise, int Ftot, int HW,
+                         int halves, float guidance, float alpha_t, float alpha_prev, float eta, void* stream);
+
 /* Dispatch queries (no device access, nothing launched): which kernel the automatic dispatch of md_gemm_f16 / md_conv3x3_nhwc_f16
  * selects for a problem on a chip with `ncu` compute units, for dense 16-byte aligned operands.  epi: bit 0 residual, bit 1
  * row-broadcast operand, bit 2 bias.  Returns 1MN gemm_sp_kernel with wave tile (MT, NT) = (M, N) (135 = 192x320, 134 = 192x256,

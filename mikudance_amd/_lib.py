@@ -37,6 +37,7 @@ SIGNATURES = {
     "md_concat_channels_f16": (c_int, [P, c_int, P, c_int, P, c_long, P]),
     "md_window_accumulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "md_cfg_ddim_step": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P]),
+    "md_cfg_ddim_step_eta": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P]),
 }
 
 _lib = None

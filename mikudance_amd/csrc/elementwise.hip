@@ -102,8 +102,9 @@ extern "C" int md_window_accumulate(const void* pred, void* noise_sum, void* cou
 //   x0  = sqrt(a_t) x - sqrt(1-a_t) v ;  eps = sqrt(a_t) v + sqrt(1-a_t) x
 //   x'  = sqrt(a_prev) x0 + sqrt(1-a_prev) eps                                      DDIMScheduler.step
 // latents: [Ftot][HW][4] fp16, updated in place (fp32 arithmetic, one rounding).
-__global__ void cfg_ddim_kernel(half_t* __restrict__ lat, const float* __restrict__ noise_sum, const float* __restrict__ counter, int Ftot, int HW4,
-                                int halves, float guidance, float sa, float sb, float sap, float sbp) {
+__global__ void cfg_ddim_kernel(half_t* __restrict__ lat, const float* __restrict__ noise_sum, const float* __restrict__ counter,
+                                const half_t* __restrict__ variance_noise, int Ftot, int HW4, int halves, float guidance, float sa, float sb, float sap,
+                                float sdir, float sigma) {
   const long total = (long)Ftot * HW4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int fr = (int)(idx / HW4);
@@ -118,19 +119,38 @@ __global__ void cfg_ddim_kernel(half_t* __restrict__ lat, const float* __restric
     const float x = (float)lat[idx];
     const float x0 = sa * x - sb * v;
     const float ep = sa * v + sb * x;
-    lat[idx] = (half_t)(sap * x0 + sbp * ep);
+    float out = sap * x0 + sdir * ep;                              // sdir = sqrt(1 - alpha_prev - sigma^2)
+    if (variance_noise) out += sigma * (float)variance_noise[idx];  // eta > 0: + sigma_t * z
+    lat[idx] = (half_t)out;
   }
+}
+
+static int cfg_ddim_launch(void* latents, const void* noise_sum, const void* counter, const void* variance_noise, int Ftot, int HW, int halves,
+                           float guidance, float alpha_t, float alpha_prev, float eta, void* stream, const char* who) {
+  MD_CHECK_ARG(Ftot > 0 && HW > 0 && (halves == 1 || halves == 2) && eta >= 0.f && (eta == 0.f || variance_noise), "md_cfg_ddim_step: bad arguments");
+  // diffusers DDIMScheduler._get_variance: sigma_t^2 = eta^2 (1 - a_prev) / (1 - a_t) (1 - a_t / a_prev); a_t == 1 never occurs (t >= 0 of a
+  // zero-terminal-SNR table has a_t < 1)
+  const float var = eta > 0.f ? (1.f - alpha_prev) / (1.f - alpha_t) * (1.f - alpha_t / alpha_prev) : 0.f;
+  const float sigma = eta * sqrtf(var > 0.f ? var : 0.f);
+  const float dir2 = 1.f - alpha_prev - sigma * sigma;
+  const long total = (long)Ftot * HW * 4;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (half_t*)latents, (const float*)noise_sum, (const float*)counter,
+                     eta > 0.f ? (const half_t*)variance_noise : nullptr, Ftot, HW * 4, halves, guidance, sqrtf(alpha_t), sqrtf(1.f - alpha_t),
+                     sqrtf(alpha_prev), sqrtf(dir2 > 0.f ? dir2 : 0.f), sigma);
+  MD_CHECK_LAUNCH(who);
+  return MD_OK;
 }
 
 extern "C" int md_cfg_ddim_step(void* latents, const void* noise_sum, const void* counter, int Ftot, int HW, int halves, float guidance, float alpha_t,
                                 float alpha_prev, void* stream) {
-  MD_CHECK_ARG(Ftot > 0 && HW > 0 && (halves == 1 || halves == 2), "md_cfg_ddim_step: bad arguments");
-  const long total = (long)Ftot * HW * 4;
-  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (half_t*)latents, (const float*)noise_sum, (const float*)counter, Ftot,
-                     HW * 4, halves, guidance, sqrtf(alpha_t), sqrtf(1.f - alpha_t), sqrtf(alpha_prev), sqrtf(1.f - alpha_prev));
-  MD_CHECK_LAUNCH("md_cfg_ddim_step");
-  return MD_OK;
+  return cfg_ddim_launch(latents, noise_sum, counter, nullptr, Ftot, HW, halves, guidance, alpha_t, alpha_prev, 0.f, stream, "md_cfg_ddim_step");
+}
+
+extern "C" int md_cfg_ddim_step_eta(void* latents, const void* noise_sum, const void* counter, const void* variance_noise, int Ftot, int HW, int halves,
+                                    float guidance, float alpha_t, float alpha_prev, float eta, void* stream) {
+  return cfg_ddim_launch(latents, noise_sum, counter, variance_noise, Ftot, HW, halves, guidance, alpha_t, alpha_prev, eta, stream,
+                         "md_cfg_ddim_step_eta");
 }
 
 // ---- generic strided scatter of NHWC fp16 -> any layout/dtype (API boundary: UNet.forward returns NCFHW) ---------------

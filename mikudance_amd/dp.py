@@ -72,9 +72,28 @@ def barrier():
             dist.barrier()
 
 
-def max_over_ranks(value, device):
+def _reduce(value, device, op):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # fp32 on the wire (RCCL reduces it natively on every build; fp64 is the rarer code path and nothing here needs it)
+    t = torch.tensor([value], dtype=torch.float32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=op)
     return float(t.item())
+
+
+def max_over_ranks(value, device):
+    return _reduce(value, device, dist.ReduceOp.MAX)
+
+
+def sum_over_ranks(value, device):
+    return _reduce(value, device, dist.ReduceOp.SUM)
+
+
+def shutdown():
+    """Every rank leaves the job the same way (also on an exception): a rank that returns without destroy_process_group() makes
+    RCCL's watchdog of the others log aborts, or hang them inside their last collective."""
+    if dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:                                   # noqa: BLE001 -- shutting down after a failure must not mask it
+            pass

@@ -206,7 +206,14 @@ def window_accumulate(pred, noise_sum, counter, window, f, ftot, hw, halves=2):
               hw, halves, _st())
 
 
-def cfg_ddim_step(latents, noise_sum, counter, ftot, hw, guidance, alpha_t, alpha_prev, halves=2):
+def cfg_ddim_step(latents, noise_sum, counter, ftot, hw, guidance, alpha_t, alpha_prev, halves=2, eta=0.0, variance_noise=None):
+    """eta > 0: `variance_noise` is the caller's N(0, 1) draw, fp16, laid out like `latents` (ftot, hw, 4)."""
     _chk(latents, "latents"); _chk(noise_sum, "noise_sum", torch.float32); _chk(counter, "counter", torch.float32)
+    if eta:
+        _chk(variance_noise, "variance_noise")
+        assert variance_noise is not None and variance_noise.is_contiguous() and variance_noise.numel() == latents.numel()
+        _lib.call("md_cfg_ddim_step_eta", latents.data_ptr(), noise_sum.data_ptr(), counter.data_ptr(), variance_noise.data_ptr(), ftot,
+                  hw, halves, float(guidance), float(alpha_t), float(alpha_prev), float(eta), _st())
+        return
     _lib.call("md_cfg_ddim_step", latents.data_ptr(), noise_sum.data_ptr(), counter.data_ptr(), ftot, hw, halves,
               float(guidance), float(alpha_t), float(alpha_prev), _st())

@@ -120,12 +120,14 @@ class MikuDanceVideoPipeline:
     # ------------------------------------------------------------------------------------------ the hot path
     @torch.no_grad()
     def denoise(self, latents, ref_latents, image_prompt_embeds, num_inference_steps, guidance_scale, context_schedule="uniform",
-                context_frames=None, context_stride=1, context_overlap=8, callback=None, callback_steps=1):
+                context_frames=None, context_stride=1, context_overlap=8, callback=None, callback_steps=1, eta=0.0, generator=None):
         """The loop of reference src/pipelines/pipeline_mikudance.py:573-686.
 
         latents             (1, 4, F, h, w)  initial noise (any float dtype, on the GPU)
         ref_latents         (1, F, 22, h, w) 20 VAE-latent guidance channels + 2 scene-motion channels
         image_prompt_embeds (2, L, D) = [zeros, CLIP tokens] when guidance_scale > 1, else (1, L, D)
+        eta, generator      DDIM's stochastic variant (reference :152-171 -> scheduler.step(eta=, generator=)): one N(0, 1) draw of
+                            the latents' shape and dtype per step from `generator` (on ITS device, like diffusers' randn_tensor)
         returns latents (1, 4, F, h, w) in the input dtype.
         """
         dev = latents.device
@@ -190,7 +192,13 @@ class MikuDanceVideoPipeline:
                     reader.clear()
                     writer.clear()
                 a_t, a_prev = sch.step_coefficients(t)
-                ops.cfg_ddim_step(lat, noise_sum, counter, F_, HW, guidance_scale, a_t, a_prev, halves=nb)
+                z = None
+                if eta > 0:
+                    from .scheduler import randn_tensor
+                    zn = randn_tensor(latents.shape, generator=generator, device=dev, dtype=latents.dtype)      # (1, 4, F, h, w)
+                    zs = zn.stride()
+                    z = ops.pack_nhwc(zn, F_, F_, (0, zs[2], zs[1], zs[3], zs[4]), 0, c, 4, hh, ww)
+                ops.cfg_ddim_step(lat, noise_sum, counter, F_, HW, guidance_scale, a_t, a_prev, halves=nb, eta=float(eta), variance_noise=z)
                 if callback is not None and step_i % callback_steps == 0:
                     callback(step_i, t, self._latents_out(lat, latents))
         finally:
@@ -313,9 +321,12 @@ class MikuDanceVideoPipeline:
                  return_dict: bool = True, callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
                  callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=None, context_stride=1,
                  context_overlap=8, context_batch_size=1, interpolation_factor=1, **kwargs):
-        if eta != 0.0 or context_batch_size != 1:
-            raise NotImplementedError("eta != 0 and context_batch_size != 1 are never used by scripts/inference_video.py "
-                                      "(SURVEY.md component 3b)")
+        # context_batch_size: the reference concatenates that many windows along the batch axis (:601-622).  With one window per
+        # context batch (every clip of <= context_frames frames, whatever the value) that is the evaluation below; with two or
+        # more windows in a batch the reference itself fails at `noise_pred[:, :, c] + pred` (:662, batch 2 vs 2k), so there is
+        # no behaviour to reproduce: the windows are evaluated one at a time here, which is what the sum over a batch would be.
+        if context_batch_size < 1:
+            raise ValueError(f"context_batch_size must be >= 1, got {context_batch_size}")
         height = height or 768
         width = width or 768
         device = self._execution_device
@@ -335,7 +346,7 @@ class MikuDanceVideoPipeline:
         tracker = torch.from_numpy(np.asarray(scene_motion_npy)).to(dtype=ref_image_latents.dtype, device=ref_image_latents.device)
         ref_latents = torch.cat([ref_image_latents, pose_ref_latents, pose_tgt, face_tgt, hand_tgt, tracker], dim=1)[None]
         latents = self.denoise(latents, ref_latents, image_prompt_embeds, num_inference_steps, guidance_scale, context_schedule,
-                               context_frames, context_stride, context_overlap, callback, callback_steps)
+                               context_frames, context_stride, context_overlap, callback, callback_steps, eta=eta, generator=generator)
         if interpolation_factor > 0:
             latents = self.interpolate_latents(latents, interpolation_factor, device)
         images = self.decode_temporal(latents) if self.video_decoder else self.decode_latents(latents)

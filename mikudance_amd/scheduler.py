@@ -1,12 +1,21 @@
 """DDIMScheduler -- host-side mirror of diffusers==0.24.0 DDIMScheduler for the configuration MikuDance uses
 (reference configs/inference/mikudance_config.yaml:24-33; constructed at scripts/inference_video.py:101-102):
-linear betas rescaled to zero terminal SNR, v-prediction, trailing timestep spacing, eta = 0.
+linear betas rescaled to zero terminal SNR, v-prediction, trailing timestep spacing; eta = 0 (the script's default) or eta > 0.
 The table is 1000 fp32 scalars on the host; the per-step arithmetic on the latents is the HIP kernel
 md_cfg_ddim_step (fused with window averaging and classifier-free guidance)."""
 from dataclasses import dataclass
 
 import numpy as np
 import torch
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """diffusers.utils.torch_utils.randn_tensor for one generator: the draw happens on the GENERATOR's device (a CPU generator ->
+    CPU draw, then moved: what scripts/inference_video.py's torch.manual_seed generator gives) so that results do not depend
+    on where the model lives."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    gdev = generator.device if generator is not None else device
+    return torch.randn(tuple(shape), generator=generator, device=gdev, dtype=dtype).to(device)
 
 
 @dataclass
@@ -67,8 +76,6 @@ class DDIMScheduler:
              variance_noise=None, return_dict: bool = True):
         """API-compatible step on GPU tensors of any shape (the fused pipeline calls md_cfg_ddim_step directly with
         window averaging and guidance folded in; this entry runs the same kernel without them)."""
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 is never used by MikuDance")
         from . import ops
         if not sample.is_cuda or sample.numel() % 4:
             raise RuntimeError("DDIMScheduler.step: tensors must live on the GPU (no CPU path)")
@@ -77,7 +84,15 @@ class DDIMScheduler:
         lat = sample.detach().to(torch.float16).reshape(1, n, 4).contiguous().clone()
         v = model_output.detach().to(torch.float32).reshape(1, 1, n, 4).contiguous()
         one = torch.ones((1,), device=sample.device, dtype=torch.float32)
-        ops.cfg_ddim_step(lat, v, one, 1, n, 1.0, a_t, a_prev, halves=1)
+        z = None
+        if eta > 0:
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"
+                                 " `variance_noise` stays `None`.")
+            if variance_noise is None:
+                variance_noise = randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+            z = variance_noise.detach().to(device=sample.device, dtype=torch.float16).reshape(1, n, 4).contiguous()
+        ops.cfg_ddim_step(lat, v, one, 1, n, 1.0, a_t, a_prev, halves=1, eta=float(eta), variance_noise=z)
         prev = lat.reshape(sample.shape).to(sample.dtype)
         if not return_dict:
             return (prev,)

@@ -18,6 +18,21 @@ SCHED_KWARGS = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", 
                     prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
 
 
+def _cache_file(cls, geom, kw, seed, mode):
+    """Synthetic fp16 weights are a pure function of (class, geometry, seed, mode): tests and bench.py build the same 2.2 G
+    parameters in up to six processes per run (25-40 s of CPU randn each), so the fp16 copy is kept under the system temp
+    directory and mapped back by later builds.  MD_SYNTH_CACHE=0 switches it off; nothing but seeded random weights ever goes
+    through it (real checkpoints load through from_pretrained_2d / load_state_dict)."""
+    import hashlib
+    import tempfile
+    if os.environ.get("MD_SYNTH_CACHE", "1") == "0":
+        return None
+    key = hashlib.sha1(repr((cls.__name__, sorted(geom.items()), sorted((k, repr(v)) for k, v in kw.items()), seed, mode, 2)).encode()).hexdigest()[:16]
+    d = os.path.join(tempfile.gettempdir(), "mdance_synth_cache")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, f"{cls.__name__}_{key}_f16.safetensors")
+
+
 def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device="cuda", dtype=torch.float16, keep_state_dicts=True):
     """Both UNets with seeded synthetic weights (no checkpoints exist offline).  Returns (ref, den, ref_sd, den_sd); the fp32
     state dicts are dropped (None) unless keep_state_dicts -- they are only needed to feed the CPU oracle.  One model at a
@@ -27,12 +42,30 @@ def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device=
     geom = dict(SMALL if geom is None else geom)
     out = []
     for cls, kw, seed in ((UNet2DConditionModel, {}, seed_ref), (UNet3DConditionModel, MM_KWARGS, seed_den)):
+        cache = _cache_file(cls, geom, kw, seed, mode) if dtype == torch.float16 else None
+        if cache is not None and not keep_state_dicts and os.path.exists(cache):
+            from safetensors.torch import load_file
+            with torch.device("meta"):
+                model = cls(sample_size=16, **geom, **kw)
+            model.load_state_dict(load_file(cache, device="cpu"), strict=True, assign=True)
+            out.append((model.to(device=device), None))
+            continue
         with torch.device("meta"):
             shapes = {k: tuple(v.shape) for k, v in cls(sample_size=16, **geom, **kw).state_dict().items()}
         sd = synth_state_dict(shapes, seed=seed, mode=mode)
         model = cls(sample_size=16, **geom, **kw)
         model.load_state_dict(sd, strict=True)
-        model = model.to(device=device, dtype=dtype)
+        model = model.to(dtype=dtype)
+        if cache is not None and not os.path.exists(cache) and sum(v.numel() for v in sd.values()) > 50_000_000 \
+                and os.environ.get("LOCAL_RANK", "0") == "0":              # one writer per host
+            from safetensors.torch import save_file
+            tmp = f"{cache}.{os.getpid()}.tmp"
+            try:
+                save_file({k: v.contiguous() for k, v in model.state_dict().items()}, tmp)
+                os.replace(tmp, cache)
+            except OSError:
+                pass                                                   # a full or read-only temp directory only costs the next build its time
+        model = model.to(device=device)
         out.append((model, sd if keep_state_dicts else None))
         del sd
     (ref, ref_sd), (den, den_sd) = out

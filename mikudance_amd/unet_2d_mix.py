@@ -114,14 +114,20 @@ class UNet2DConditionModel(_UNet2DBase):
         return newnet
 
     # ------------------------------------------------------------------------------------------ internal NHWC forward
-    def forward_nhwc(self, x, motion_at, cross):
+    def forward_nhwc(self, x, motion_at, cross, timesteps=None):
         """x: (B, h, w, 64) fp16 (20 guidance channels, zero padded); motion_at(h', w') -> (B, h', w', 64) nearest
-        resized scene-motion map; t == 0 always (pipeline_mikudance.py:649).  Returns the (unused) sample."""
+        resized scene-motion map; timesteps: None (t = 0, what the pipeline passes: pipeline_mikudance.py:649), one value, or
+        one value per sample.  Returns the (unused) sample."""
         pk = self.packed()
         dev = x.device
         B, hh, ww, _ = x.shape
         force_size = self._needs_upsample_size(hh, ww, len(self.down_blocks))
-        trows = self._time_rows(pk, torch.zeros(1), dev)                     # one group: every frame shares t = 0
+        t = torch.zeros(1) if timesteps is None else torch.as_tensor(timesteps, dtype=torch.float32).reshape(-1).cpu()
+        if t.numel() > 1 and bool((t == t[0]).all()):
+            t = t[:1]
+        assert t.numel() in (1, B), f"timestep: one value or one per sample ({B}), got {t.numel()}"
+        trows = self._time_rows(pk, t, dev)                                  # one group (every frame shares t) or one per frame
+        fpg = B // t.numel()                                                 # frames per time-embedding row
         blocks = self.transformer_blocks_in_order()
         # last bank writer in EXECUTION order (down -> mid -> up): the last attention of the last up block
         last_writer = self.up_blocks[-1].attentions[-1].transformer_blocks[0] \
@@ -131,7 +137,7 @@ class UNet2DConditionModel(_UNet2DBase):
         skips = [x]
         for i, blk in enumerate(self.down_blocks):
             for j, r in enumerate(blk.resnets):
-                x = r(x, self._temb(pk, trows, r), B * x.shape[1] * x.shape[2])
+                x = r(x, self._temb(pk, trows, r), fpg * x.shape[1] * x.shape[2])
                 if blk.has_cross_attention:
                     x = blk.attentions[j](x, cross)
                 skips.append(x)
@@ -141,13 +147,13 @@ class UNet2DConditionModel(_UNet2DBase):
             # MAN after the skips were captured (quirk 10, src/models/unet_2d_mix.py:1272-1289)
             x = self.man_blocks[i](x, motion_at(x.shape[1], x.shape[2]))
         mb = self.mid_block
-        x = mb.resnets[0](x, self._temb(pk, trows, mb.resnets[0]), B * x.shape[1] * x.shape[2])
+        x = mb.resnets[0](x, self._temb(pk, trows, mb.resnets[0]), fpg * x.shape[1] * x.shape[2])
         x = mb.attentions[0](x, cross)
-        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), B * x.shape[1] * x.shape[2])
+        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), fpg * x.shape[1] * x.shape[2])
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 x = ops.concat_channels(x, skips.pop())
-                x = r(x, self._temb(pk, trows, r), B * x.shape[1] * x.shape[2])
+                x = r(x, self._temb(pk, trows, r), fpg * x.shape[1] * x.shape[2])
                 if blk.has_cross_attention:
                     tb = blk.attentions[j].transformer_blocks[0]
                     if self.skip_dead_tail and tb is last_writer:
@@ -170,9 +176,8 @@ class UNet2DConditionModel(_UNet2DBase):
                 mid_block_additional_residual=None, down_intrablock_additional_residuals=None, encoder_attention_mask=None,
                 return_dict: bool = True):
         """sample: (B, 22, h, w) = 20 character-guidance channels + 2 scene-motion channels (:1208-1210)."""
-        if float(torch.as_tensor(timestep).float().abs().max()) != 0.0:
-            raise NotImplementedError("reference_unet is only ever evaluated at t = 0 (pipeline_mikudance.py:649)")
         B, c, hh, ww = sample.shape
+        t = torch.as_tensor(timestep).reshape(-1).float().cpu()             # scalar or (B,) (reference :1058-1072 expands a scalar)
         nchar = c - 2
         st = sample.stride()
         x = ops.pack_nhwc(sample, B, 1, (st[0], 0, st[1], st[2], st[3]), 0, nchar, 64, hh, ww)
@@ -182,7 +187,7 @@ class UNet2DConditionModel(_UNet2DBase):
 
         ctx = encoder_hidden_states
         cross = self._cross(ctx, list(range(B)) if ctx.shape[0] == B else [0] * B, sample.device)
-        y = self.forward_nhwc(x, motion_at, cross)
+        y = self.forward_nhwc(x, motion_at, cross, timesteps=t)
         if y is None:
             out = None
         else:

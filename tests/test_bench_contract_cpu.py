@@ -69,3 +69,25 @@ def test_command_line_defaults():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert re.search(r'"--gpus", type=int, default=1\b', src) and re.search(r'"--size", type=int, default=768\b', src)
     assert re.search(r'"--frames", type=int, default=16\b', src) and re.search(r'"--ddim-steps", type=int, default=20\b', src)
+
+
+def test_two_rank_launch_protocol_under_gloo():
+    """bench.py exactly as the driver launches it for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2 ...), on CPU
+    with the gloo backend and the kernels replaced by a stand-in (--dry-run-cpu): rendezvous, rank-local staging AND the
+    --scatter variant, barrier / max-over-ranks timing, gather on rank 0, ONE JSON line from rank 0 only, every rank exits 0
+    through destroy_process_group()."""
+    import socket
+    for extra in ([], ["--scatter"]):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small",
+               "--dry-run-cpu", "--size", "128", "--frames", "4", "--ddim-steps", "2"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["clips_gathered"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+        assert d["value"] is None and "dry-run" in d["data"] and d["config"]["parallelism"] == "dp2"
+        assert d["config"]["input_staging"] == ("scatter" if extra else "rank-local")
+        assert d["clip_means"][0] != d["clip_means"][1]                  # two different clips (seeds 100, 101) came back in rank order

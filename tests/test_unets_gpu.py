@@ -233,18 +233,6 @@ def test_dilated_wrapping_window_with_repeated_frames_vs_oracle(small):
     assert torch.equal(out, pipe.denoise(*args, **kw))
 
 
-@pytest.fixture(scope="module")
-def full(golden_dir):
-    """FULL-WIDTH SD-1.5 geometry, seeded weights (checksums pinned by g8_meta.json), built once for the module."""
-    meta = json.load(open(os.path.join(golden_dir, "g8_meta.json")))
-    geom = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
-    ref, den, ref_sd, den_sd = build_models(geom=geom, seed_den=meta["seed_den"], seed_ref=meta["seed_ref"])
-    cs = lambda sd: float(sum(v.double().abs().sum() for v in sd.values()))
-    assert abs(cs(den_sd) - meta["checksum_den"]) < 1e-6 * meta["checksum_den"]
-    assert abs(cs(ref_sd) - meta["checksum_ref"]) < 1e-6 * meta["checksum_ref"]
-    return ref, den, ref_sd, den_sd
-
-
 def _literal_pair(ref, den, lat, rl, emb, f, h, w, timestep):
     """One UNet-pair evaluation with the reference's literal call pattern (pipeline_mikudance.py:626-660)."""
     writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
@@ -424,3 +412,74 @@ def test_pipeline_call_signature_end_to_end(small):
         assert torch.isfinite(v).all() and float(v.min()) >= 0.0 and float(v.max()) <= 1.0
     with pytest.raises(ValueError):
         pipe.prepare_latents(2, 4, W, H, F_, torch.float16, "cuda", [torch.manual_seed(0)])
+
+
+def test_eta_positive_ddim_vs_oracle(small):
+    """eta > 0 (reference src/pipelines/pipeline_mikudance.py:152-171 -> scheduler.step(eta=, generator=)): one fp16 N(0, 1) draw of
+    the latents' shape per step from the caller's CPU generator (diffusers randn_tensor), sigma_t z added by md_cfg_ddim_step_eta.
+    Same seed on both sides -> same draws; the oracle restates the third-party formula (parity unpinned)."""
+    from mikudance_amd.synth import synth_inputs
+    meta, ref, den, ref_sd, den_sd, t = small
+    lat, rl, emb = (x.half().float() for x in synth_inputs(4, 16, 16, ctx_len=5, ctx_dim=64, seed=7))
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    args = (lat.cuda().half(), rl.cuda().half(), emb.cuda().half(), 4, 3.5)
+    out = pipe.denoise(*args, eta=0.7, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 4, guidance_scale=3.5, reduced=True, eta=0.7,
+                              generator=torch.Generator().manual_seed(11), noise_dtype=torch.float16)
+        plain = O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 4, guidance_scale=3.5, reduced=True)
+    r, c = rel_l2(out.float(), want), cosine(out.float(), want)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    assert rel_l2(plain, want) > 10 * r                                  # the noise term is what was matched, not the eta = 0 path
+    assert torch.equal(out, pipe.denoise(*args, eta=0.7, generator=torch.Generator().manual_seed(11)))
+    # the scheduler's own step() entry with eta, on the same draw
+    sch = DDIMScheduler(**SCHED_KWARGS)
+    sch.set_timesteps(4)
+    o = O.DDIM()
+    o.set_timesteps(4)
+    v, x = torch.randn(1, 4, 3, 8, 8).half(), torch.randn(1, 4, 3, 8, 8).half()
+    got = sch.step(v.cuda(), 749, x.cuda(), eta=0.5, generator=torch.Generator().manual_seed(5)).prev_sample
+    want = o.step(v.float(), 749, x.float(), eta=0.5, noise=torch.randn(x.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float16).float())
+    assert (got.float().cpu() - want).abs().max() <= 2e-3 * want.abs().max() + 1e-3
+
+
+def test_reference_unet_accepts_any_timestep(small):
+    """UNet2DConditionModel.forward(sample, timestep, ...) (reference src/models/unet_2d_mix.py:944-959,1058-1081) at t != 0, scalar
+    and per-sample: the pipeline only ever passes zeros_like(t), the signature takes any."""
+    meta, ref, den, ref_sd, den_sd, t = small
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 22, 16, 16, generator=g) * 0.5
+    ctx = torch.randn(4, 5, 64, generator=g)
+    for ts in (torch.tensor(500), torch.tensor([0, 250, 500, 999])):
+        got = ref(x.cuda().half(), ts, encoder_hidden_states=ctx.cuda().half(), return_dict=False)[0].float().cpu()
+        with torch.no_grad():
+            if ts.dim() == 0:
+                want = O.reference_unet_forward(ref_sd, x.half().float(), ctx.half().float(), t=ts)[1]
+            else:
+                want = torch.cat([O.reference_unet_forward(ref_sd, x[i:i + 1].half().float(), ctx[i:i + 1].half().float(), t=ts[i])[1]
+                                  for i in range(4)])
+        r, c = rel_l2(got, want), cosine(got, want)
+        assert r < 3e-2 and c > 0.999, (ts, r, c)
+    t0 = ref(x.cuda().half(), torch.tensor(0), encoder_hidden_states=ctx.cuda().half(), return_dict=False)[0].float().cpu()
+    assert rel_l2(t0, want) > 1e-2                                        # the time embedding really entered
+
+
+def test_context_batch_size_is_accepted(small):
+    """context_batch_size (reference :601-622): any value with one window per context batch is the plain evaluation."""
+    from PIL import Image
+    import numpy as np
+    meta, ref, den, ref_sd, den_sd, t = small
+    H = W = 128
+    F_ = 3
+    outs = []
+    for cbs in (1, 2):
+        rng = np.random.default_rng(0)
+        img = lambda: Image.fromarray(rng.integers(0, 255, (160, 144, 3), dtype=np.uint8))
+        flow = rng.uniform(-0.03, 0.03, (F_, 2, H // 8, W // 8))
+        pipe = MikuDanceVideoPipeline(vae=_FakeVAE(), image_encoder=_FakeCLIP(), reference_unet=ref, denoising_unet=den,
+                                      scheduler=DDIMScheduler(**SCHED_KWARGS)).to("cuda", dtype=torch.float16)
+        outs.append(pipe(img(), img(), [img() for _ in range(F_)], [img() for _ in range(F_)], [img() for _ in range(F_)], flow, W, H, F_,
+                         2, 3.5, generator=torch.manual_seed(42), context_batch_size=cbs, eta=0.0).videos)
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(ValueError):
+        pipe(img(), img(), [img()] * F_, [img()] * F_, [img()] * F_, flow, W, H, F_, 2, 3.5, context_batch_size=0)
