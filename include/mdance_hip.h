@@ -63,6 +63,16 @@ int md_conv3x3_pad_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int 
                             int stride, int upsample, int pad_lo, const void* bias, const void* residual, int ldr,
                             const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
 
+/* The general form of the two entries above: X may be a channel slice of a wider NHWC tensor (pixel pitch ldx >= Cin elements:
+ * the skip connections of the UNets are produced straight into the concat buffer of the up-block resnet that consumes them, so
+ * torch.cat([hidden, skip], 1) of src/models/unet_3d_blocks.py:736,877 / unet_2d_blocks.py never runs as a copy), and kw = 1 selects
+ * a 3 x 1 filter (taps along H only, K = 3 Cin, stride 1, pad 1): nn.Conv3d(C, C, (3,1,1), padding (1,0,0)) of the third-party
+ * AutoencoderKLTemporalDecoder (src/pipelines/pipeline_mikudance.py:132-150) on the (clips, frames, h*w, C) view, ONE launch and one
+ * rounding instead of three accumulating GEMMs. */
+int md_conv_nhwc_f16(const void* X, int ldx, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int kw,
+                     int stride, int upsample, int pad_lo, const void* bias, const void* residual, int ldr, const void* rowadd,
+                     int ldra, int rows_per_group, int act, void* stream);
+
 /* In-place softmax(scale * x) over the rows of a row-major fp16 matrix [rows][ldx] (cols valid, cols % 8 == 0).
  * The score matrix of the single 512-channel head of the AutoencoderKL mid-block attention (QK^T and PV run on
  * md_gemm_f16): src/pipelines/pipeline_mikudance.py:115-130 (decode_latents), :456-549 (vae.encode). */
@@ -73,6 +83,10 @@ int md_softmax_rows_f16(void* x, int ldx, int rows, int cols, float scale, void*
 size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G);
 int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G,
                           float eps, int silu, void* workspace, size_t ws_bytes, void* stream);
+
+/* Same with an input pixel pitch ldx >= C (x a channel slice of a wider NHWC tensor; y stays contiguous; in place only if ldx == C). */
+int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G,
+                             float eps, int silu, void* workspace, size_t ws_bytes, void* stream);
 
 /* LayerNorm over rows of C.  add_mode 0: y only.  add_mode 1: y2[row] = y[row] + add[row - add_row_begin] for
  * rows >= add_row_begin (reference-attention bank ADD, src/models/mutual_mix_attention.py:169-170), y2 = y
@@ -85,6 +99,9 @@ int md_layernorm_f16(const void* x, void* y, void* y2, const void* gamma, const 
  * src/models/man_module.py:23-33. */
 int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void* y, int B, int HW, int C, float eps,
                           void* stream);
+
+int md_instnorm_spade_ld_f16(const void* x, int ldx, const void* gamma_beta, void* y, int B, int HW, int C, float eps,
+                             void* stream);                      /* x with a pixel pitch ldx >= C (a channel slice) */
 
 /* O = softmax(Q K^T * scale) V per (batch, head); Vt is V transposed ([H*D][ldvt], md_gemm_f16 transpose_out);
  * kv_index (device int[B], may be NULL) maps a query batch to its K/V batch; kv_stride = tokens between K/V batches.

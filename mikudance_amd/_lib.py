@@ -19,11 +19,15 @@ SIGNATURES = {
                                     c_int, c_int, P]),
     "md_conv3x3_pad_nhwc_f16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
                                         c_int, c_int, c_int, P]),
+    "md_conv_nhwc_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
+                                 c_int, c_int, c_int, P]),
     "md_gemm_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "md_conv3x3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "md_softmax_rows_f16": (c_int, [P, c_int, c_int, c_int, c_float, P]),
     "md_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "md_groupnorm_nhwc_f16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
+    "md_groupnorm_ld_nhwc_f16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
+    "md_instnorm_spade_ld_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_float, P]),
     "md_layernorm_f16": (c_int, [P, P, P, P, P, P, c_int, c_int, c_float, c_int, c_int, c_int, c_int, P]),
     "md_instnorm_spade_f16": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
     "md_attention_fwd_f16": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int,

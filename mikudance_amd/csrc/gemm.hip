@@ -46,6 +46,8 @@ struct GemmParams {
   int bias_rows;          // gemm_sp_kernel on swapped operands (transposed output): bias[m] per output ROW instead of bias[n] per column
   // conv
   int Hin, Win, Cin, Hout, Wout, stride, upsample, pad;   // pad: zero rows/cols before the image (1, or 0 for the VAE downsampler)
+  int ldx;                // conv: input pixel pitch in elements (Cin, or wider when X is a channel slice of a wider NHWC tensor)
+  int kw;                 // conv: filter taps along x, 3 (3 x 3) or 1 (3 x 1: the centre column only; K = 3 Cin)
   int tiles_n, tiles_total;
   int tiles_m, group_m;   // gemm_sp_kernel: tile order (group_m row panels of tiles are walked column by column)
 };
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
       a_oy[j] = oy * p.stride - p.pad;      // input row of filter tap ky = 0 (in the possibly upsampled image)
       a_ox[j] = ox * p.stride - p.pad;
-      a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.Cin + lslot * 8;
+      a_src[j] = p.A + (size_t)b * p.Hin * p.Win * p.ldx + lslot * 8;
     } else {
       a_oy[j] = a_ox[j] = 0;
       a_src[j] = p.A + (size_t)mm * p.lda + lslot * 8;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
     char* sw = smem + stage * STAGE + OPA + (wave * IPB) * 1024;
     if (CONV) {
       const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = p.kw == 3 ? tap / 3 : tap, kx = p.kw == 3 ? tap - ky * 3 : 1;
       const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
 #pragma unroll
       for (int j = 0; j < IPA; ++j) {
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(WM * 128, WPS) void gemm_kernel(GemmParams p) {
         // for the zero page where the tap falls outside the image
         const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
         const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
-        unsigned off = __umul24(__umul24((unsigned)(iy >> p.upsample), (unsigned)p.Win) + (unsigned)(ix >> p.upsample), (unsigned)p.Cin) + c0;
+        unsigned off = __umul24(__umul24((unsigned)(iy >> p.upsample), (unsigned)p.Win) + (unsigned)(ix >> p.upsample), (unsigned)p.ldx) + c0;
         asm volatile("" : "+v"(off));
         const half_t* src = a_src[j] + off;
         src = ok ? src : zero_src;
@@ -654,6 +656,8 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
     const double c5 = ok5 ? cost(192, 320, 1.56) : 1e30, c4 = ok4 && (force_nt == 0 || force_nt == 4) ? cost(192, 256, 1.28) : 1e30,
                  c2 = ok4 && (force_nt == 0 || force_nt == 2) ? cost(128, 256, 0.95) : 1e30;
     if (c5 < 1e30 || c4 < 1e30 || c2 < 1e30) nt = c5 <= c4 && c5 <= c2 ? 5 : (c4 <= c2 ? 4 : 2);
+    // N a multiple of 128 only (the 128-channel convs of the AutoencoderKL at full resolution): the 256 x 128 tile, wave tile 128 x 64
+    else if ((force_nt == 0 || force_nt == 42) && sp_eligible<CONV, false, 2>(p)) nt = 42;
   } else if (!sp_eligible<CONV, true>(p)) {
     nt = 0;
   }
@@ -662,9 +666,10 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
       if constexpr (GEGLU) launch_sp<CONV, true>(p, stream);
       else if (nt == 4) launch_sp<CONV, false, 4>(p, stream);
       else if (nt == 2) launch_sp<CONV, false, 4, 2>(p, stream);
+      else if (nt == 42) launch_sp<CONV, false, 2, 4>(p, stream);
       else launch_sp<CONV, false, 5>(p, stream);
     }
-    return GEGLU ? 144 : (nt == 4 ? 134 : (nt == 2 ? 124 : 135));
+    return GEGLU ? 144 : (nt == 4 ? 134 : (nt == 2 ? 124 : (nt == 42 ? 142 : 135)));
   };
   if (sp == 1 && nt) return run_sp();
   // 1. HBM-bound short-K projections on long token matrices: W-stationary streaming kernel (gemm_ws.h), plain and GEGLU (K = 320)
@@ -688,7 +693,7 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
   //    the 128 x 128 kernel, M = 4608 GEMMs +1..18 %, M = 18 432 x N = 1280 +19..34 %); GEGLU GEMMs with K >= 640 (+24..29 %; at
   //    K = 320 the W-stationary kernel above is 9 % faster)
   if (sp > 0 && nt) {
-    const long tiles = (long)cdiv(p.M, GEGLU ? 256 : (nt == 2 ? 128 : 192)) * (p.N / (nt == 5 ? 320 : 256));
+    const long tiles = (long)cdiv(p.M, GEGLU || nt == 42 ? 256 : (nt == 2 ? 128 : 192)) * (p.N / (nt == 5 ? 320 : (nt == 42 ? 128 : 256)));
     const bool pick = GEGLU ? p.K >= 640 : (tiles >= 112 && (CONV || p.K >= 640));
     if (pick) return run_sp();
   }
@@ -804,26 +809,28 @@ extern "C" int md_gemm_f16(const void* A, int lda, const void* W, void* C, int l
   return launch_gemm(p, false, (hipStream_t)stream);
 }
 
-static int conv3x3_common(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int stride,
-                          int upsample, int pad_lo, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
-                          int rows_per_group, int act, void* stream) {
+static int conv_common(const void* X, int ldx, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int kw, int stride,
+                       int upsample, int pad_lo, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
+                       int rows_per_group, int act, void* stream) {
   MD_CHECK_ARG(Cin % 64 == 0, "md_conv3x3: Cin=%d must be a multiple of 64 (zero-pad channels when packing)", Cin);
+  MD_CHECK_ARG(ldx >= Cin && ldx % 8 == 0, "md_conv3x3: ldx=%d must be a multiple of 8 and >= Cin=%d", ldx, Cin);
   MD_CHECK_ARG(stride == 1 || stride == 2, "md_conv3x3: stride must be 1 or 2");
   MD_CHECK_ARG(upsample == 0 || (upsample == 1 && stride == 1), "md_conv3x3: upsample is 0 or 1 (nearest 2x) with stride 1");
   MD_CHECK_ARG(pad_lo == 1 || (pad_lo == 0 && stride == 2 && upsample == 0), "md_conv3x3: pad_lo is 1, or 0 with stride 2 (pad (0,1,0,1))");
-  // the A gather computes (iy * Win + ix) * Cin with 24-bit multiplies into a 32-bit element offset (per image)
-  MD_CHECK_ARG((long)Hin * Win < (1L << 24) && Cin < (1 << 24) && (long)Hin * Win * Cin < (1L << 32),
-               "md_conv3x3: image %dx%dx%d exceeds the tap arithmetic (Hin*Win < 2^24 pixels, Hin*Win*Cin < 2^32 elements)", Hin, Win, Cin);
+  MD_CHECK_ARG(kw == 3 || (kw == 1 && stride == 1 && upsample == 0 && pad_lo == 1), "md_conv: kw is 3, or 1 (3 x 1 filter) with stride 1, no upsample, pad 1");
+  // the A gather computes (iy * Win + ix) * ldx with 24-bit multiplies into a 32-bit element offset (per image)
+  MD_CHECK_ARG((long)Hin * Win < (1L << 24) && ldx < (1 << 24) && (long)Hin * Win * ldx < (1L << 32),
+               "md_conv3x3: image %dx%dx%d exceeds the tap arithmetic (Hin*Win < 2^24 pixels, Hin*Win*ldx < 2^32 elements)", Hin, Win, ldx);
   GemmParams p = {};
   p.A = (const half_t*)X; p.W = (const half_t*)W; p.C = (half_t*)Y;
   p.bias = (const half_t*)bias; p.residual = (const half_t*)residual; p.rowadd = (const half_t*)rowadd;
   p.ldc = ldy; p.ldr = ldr; p.ldra = ldra; p.lda = Cin;
-  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample; p.pad = pad_lo;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample; p.pad = pad_lo; p.ldx = ldx; p.kw = kw;
   const int hup = Hin << upsample, wup = Win << upsample;
   p.Hout = (hup + pad_lo + 1 - 3) / stride + 1;
-  p.Wout = (wup + pad_lo + 1 - 3) / stride + 1;
+  p.Wout = kw == 3 ? (wup + pad_lo + 1 - 3) / stride + 1 : Win;
   MD_CHECK_ARG(p.Hout > 0 && p.Wout > 0, "md_conv3x3: empty output %dx%d", p.Hout, p.Wout);
-  p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
+  p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 3 * kw * Cin;
   p.rows_per_group = rows_per_group; p.act = act; p.transpose_out = 0;
   return launch_gemm(p, true, (hipStream_t)stream);
 }
@@ -831,13 +838,19 @@ static int conv3x3_common(const void* X, const void* W, void* Y, int ldy, int B,
 extern "C" int md_conv3x3_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int stride,
                                    int upsample, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
                                    int rows_per_group, int act, void* stream) {
-  return conv3x3_common(X, W, Y, ldy, B, Hin, Win, Cin, Cout, stride, upsample, 1, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
+  return conv_common(X, Cin, W, Y, ldy, B, Hin, Win, Cin, Cout, 3, stride, upsample, 1, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
 }
 
 extern "C" int md_conv3x3_pad_nhwc_f16(const void* X, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout,
                                        int stride, int upsample, int pad_lo, const void* bias, const void* residual, int ldr,
                                        const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
-  return conv3x3_common(X, W, Y, ldy, B, Hin, Win, Cin, Cout, stride, upsample, pad_lo, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
+  return conv_common(X, Cin, W, Y, ldy, B, Hin, Win, Cin, Cout, 3, stride, upsample, pad_lo, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
+}
+
+extern "C" int md_conv_nhwc_f16(const void* X, int ldx, const void* W, void* Y, int ldy, int B, int Hin, int Win, int Cin, int Cout, int kw, int stride,
+                                int upsample, int pad_lo, const void* bias, const void* residual, int ldr, const void* rowadd, int ldra,
+                                int rows_per_group, int act, void* stream) {
+  return conv_common(X, ldx, W, Y, ldy, B, Hin, Win, Cin, Cout, kw, stride, upsample, pad_lo, bias, residual, ldr, rowadd, ldra, rows_per_group, act, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dispatch queries
@@ -865,7 +878,7 @@ extern "C" int md_conv3x3_plan(int B, int Hin, int Win, int Cin, int Cout, int s
   p.A = plan_ptr(0); p.W = plan_ptr(1); p.C = const_cast<half_t*>(plan_ptr(2));
   p.residual = (epi & 1) ? plan_ptr(3) : nullptr; p.rowadd = (epi & 2) ? plan_ptr(4) : nullptr; p.bias = (epi & 4) ? plan_ptr(5) : nullptr;
   p.ldc = Cout; p.ldr = Cout; p.ldra = Cout; p.lda = Cin;
-  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample; p.pad = 1;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = stride; p.upsample = upsample; p.pad = 1; p.ldx = Cin; p.kw = 3;
   p.Hout = ((Hin << upsample) + 2 - 3) / stride + 1;
   p.Wout = ((Win << upsample) + 2 - 3) / stride + 1;
   p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.rows_per_group = p.Hout * p.Wout; p.act = ACT_NONE;

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   unsigned a_voff[PA], w_voff[PB];                 // per-lane byte offsets of this wave's pieces
   int a_oy[PA], a_ox[PA];                          // conv: input row / column of filter tap (0, 0) of the lane's output pixel
   unsigned a_img[PA];                              // conv: byte offset of the lane's image + its 16-byte slot
-  int ia_it = 0, ia_kt = 0, ia_k0 = 0, ia_c0 = 0, ia_ky = 0, ia_kx = 0, ia_slot = 0;   // A stream: next tile to issue
+  const int kx0 = CONV && p.kw == 1 ? 1 : 0;       // 3 x 1 filter: the centre column is the only tap along x
+  int ia_it = 0, ia_kt = 0, ia_k0 = 0, ia_c0 = 0, ia_ky = 0, ia_kx = kx0, ia_slot = 0;   // A stream: next tile to issue
   int iw_it = 0, iw_kt = 0, iw_k0 = 0, iw_slot = 0;                                   // W stream
   // per-lane offset of piece j for filter tap (ky, kx): once per tap (every Cin / 64 K tiles), not per K tile.  All pieces at once
   // at the tap change: the burst holds the MFMAs up for ~440 cycles (profiles/r03_sp_trace.log), but spreading it over the piece
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     const unsigned hup = p.Hin << p.upsample, wup = p.Win << p.upsample;
     const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
     const bool ok = (unsigned)iy < hup && (unsigned)ix < wup;
-    const unsigned off = (((unsigned)(iy >> p.upsample) * (unsigned)p.Win + (unsigned)(ix >> p.upsample)) * (unsigned)p.Cin) * 2u + a_img[j];
+    const unsigned off = (((unsigned)(iy >> p.upsample) * (unsigned)p.Win + (unsigned)(ix >> p.upsample)) * (unsigned)p.ldx) * 2u + a_img[j];
     a_voff[j] = ok ? off : OOB;
   };
   auto conv_tap_offsets = [&]() {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
         a_oy[j] = oy * p.stride - p.pad;
         a_ox[j] = ox * p.stride - p.pad;
-        a_img[j] = (unsigned)b * (unsigned)(p.Hin * p.Win) * (unsigned)p.Cin * 2u + lslot * 16;   // < 2^31 (sp_eligible)
+        a_img[j] = (unsigned)b * (unsigned)(p.Hin * p.Win) * (unsigned)p.ldx * 2u + lslot * 16;   // < 2^31 (sp_eligible)
       } else {
         a_voff[j] = (unsigned)mm * (unsigned)p.lda * 2u + lslot * 16;                             // < 2^31 (sp_eligible)
       }
@@ -307,13 +308,15 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       ia_c0 += BK;
       if (ia_c0 == p.Cin) {
         ia_c0 = 0;
-        if (++ia_kx == 3) { ia_kx = 0; ++ia_ky; }
+        if (p.kw == 1) ++ia_ky;
+        else if (++ia_kx == 3) { ia_kx = 0; ++ia_ky; }
         if (ia_kt + 1 < nk) conv_tap_offsets();
       }
     }
     if (++ia_kt == nk) {
       ia_kt = 0;
-      ia_k0 = ia_c0 = ia_ky = ia_kx = 0;
+      ia_k0 = ia_c0 = ia_ky = 0;
+      ia_kx = kx0;
       if (++ia_it < ntile) set_sources_a(ia_it);    // past the last tile: keep its offsets (valid addresses, data never read)
       else if (CONV) conv_tap_offsets();
     }
@@ -533,7 +536,7 @@ static bool sp_eligible(const GemmParams& p) {
   if (!GEGLU && p.act != ACT_NONE) return false;
   if (CONV && p.Cin % 64 != 0) return false;
   // the DMA pieces address A and W through buffer descriptors with 32-bit byte offsets; offsets from 2^31 up mean "outside"
-  const unsigned long long a_bytes = CONV ? (unsigned long long)cdiv(p.M, p.Hout * p.Wout) * p.Hin * p.Win * p.Cin * 2
+  const unsigned long long a_bytes = CONV ? (unsigned long long)cdiv(p.M, p.Hout * p.Wout) * p.Hin * p.Win * p.ldx * 2
                                           : ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2;
   if (a_bytes >= (1ull << 31) || (unsigned long long)p.N * p.K * 2 >= (1ull << 31)) return false;
   if (!al16(p.C) || p.ldc % 8 != 0) return false;

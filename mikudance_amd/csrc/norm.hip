@@ -27,15 +27,15 @@ __device__ __forceinline__ void norm_store(T* p, const T& v) { *p = v; }
 // span more than two groups) and its slab-0 workgroups hand it to the apply sweep through the workspace (bit-identical on both sides,
 // and safe when the apply sweep runs in place).
 // Thread (cc, r): channel chunk cc (8 channels), row lane r.  A block owns `slab` consecutive pixels of one image.
-__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, float* __restrict__ pilot, int HW, int C, int G, int R, int slab,
-                                int nslab) {
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, float* __restrict__ pilot, int HW, int C, int ldx, int G, int R,
+                                int slab, int nslab) {
   extern __shared__ float sh[];  // [R][C] sums, then [R][C] sumsq
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
   const int b = blockIdx.y, sl = blockIdx.x;
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
   const int cpg = C / G;
-  const half_t* ximg = x + (size_t)b * HW * C;
+  const half_t* ximg = x + (size_t)b * HW * ldx;          // ldx: pixel pitch (C, or wider when x is a channel slice of a wider tensor)
   float s[8], q[8], k[8];
   if (cpg >= 8) {                // the 8 channels of a thread lie in at most two groups
     const int g0 = (cc * 8) / cpg, g1 = (cc * 8 + 7) / cpg;
@@ -48,10 +48,10 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-  const half_t* base = x + (size_t)b * HW * C + cc * 8;
+  const half_t* base = ximg + cc * 8;
 #pragma unroll GN_UNROLL
   for (int p = p0 + r; p < p1; p += R) {
-    const half8_t v = *reinterpret_cast<const half8_t*>(base + (size_t)p * C);
+    const half8_t v = *reinterpret_cast<const half8_t*>(base + (size_t)p * ldx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float f = (float)v[e] - k[e];
@@ -84,7 +84,8 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
 }
 
 __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restrict__ part, const float* __restrict__ pilot, const half_t* __restrict__ gamma,
-                                const half_t* __restrict__ beta, int HW, int C, int G, int R, int slab, int nslab, float eps, int silu, int zigzag) {
+                                const half_t* __restrict__ beta, int HW, int C, int ldx, int G, int R, int slab, int nslab, float eps, int silu,
+                                int zigzag) {
   __shared__ float mean_s[64], rstd_s[64];
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
@@ -115,10 +116,10 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
     sf[e] = (float)beta[c] - mean_s[g] * sc[e];
   }
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
-  const size_t base = (size_t)b * HW * C + cc * 8;
+  const size_t base = (size_t)b * HW * C + cc * 8, xbase = (size_t)b * HW * ldx + cc * 8;
 #pragma unroll GN_UNROLL
   for (int p = p0 + r; p < p1; p += R) {
-    const half8_t v = *reinterpret_cast<const half8_t*>(x + base + (size_t)p * C);
+    const half8_t v = *reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx);
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -148,9 +149,11 @@ extern "C" size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
   return ((size_t)B * nslab * G * 2 + (size_t)B * G) * sizeof(float);       // partial sums + one pilot per (image, group)
 }
 
-extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps, int silu,
-                                     void* workspace, size_t ws_bytes, void* stream) {
+extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
+                                        int silu, void* workspace, size_t ws_bytes, void* stream) {
   MD_CHECK_ARG(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0, "md_groupnorm: need C %% 8 == 0, G <= 64, C %% G == 0 (C=%d G=%d)", C, G);
+  MD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ldx == C || x != y),
+               "md_groupnorm: ldx=%d must be a multiple of 8 and >= C=%d, x 16-byte aligned; in place only with ldx == C", ldx, C);
   MD_CHECK_ARG(C / 8 <= 1024, "md_groupnorm: C=%d too large", C);
   MD_CHECK_ARG(ws_bytes >= md_groupnorm_workspace_bytes(B, HW, C, G), "md_groupnorm: workspace too small");
   const int cch = C / 8;
@@ -163,11 +166,16 @@ extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, 
   const dim3 grid(nslab, B), block(cch * R);
   const size_t sh = (size_t)2 * R * C * sizeof(float);
   float* pilot = (float*)workspace + (size_t)B * nslab * G * 2;
-  hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, pilot, HW, C, G, R, slab, nslab);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, pilot, HW, C, ldx, G, R, slab, nslab);
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const float*)pilot,
-                     (const half_t*)gamma, (const half_t*)beta, HW, C, G, R, slab, nslab, eps, silu, zigzag);
+                     (const half_t*)gamma, (const half_t*)beta, HW, C, ldx, G, R, slab, nslab, eps, silu, zigzag);
   MD_CHECK_LAUNCH("md_groupnorm");
   return MD_OK;
+}
+
+extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps, int silu,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+  return md_groupnorm_ld_nhwc_f16(x, C, y, gamma, beta, B, HW, C, G, eps, silu, workspace, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -293,18 +301,18 @@ extern "C" int md_layernorm_f16(const void* x, void* y, void* y2, const void* ga
 // ------------------------------------------------------------------------------------------------ InstanceNorm + SPADE
 // Block = 64 channels (8 chunks) x 32 row lanes of one image; two passes over HW (second pass is L2 resident).
 __global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gb, half_t* __restrict__ y, int HW,
-                                                             int C, float eps) {
+                                                             int C, int ldx, float eps) {
   __shared__ float ss[32][64], sq[32][64], mean_s[64], rstd_s[64];
   const int cc = threadIdx.x & 7, r = threadIdx.x >> 3;
   const int b = blockIdx.y, c0 = blockIdx.x * 64 + cc * 8;
-  const half_t* xb = x + (size_t)b * HW * C + c0;
+  const half_t* xb = x + (size_t)b * HW * ldx + c0;
   // sums of (x - k), (x - k)^2 with k = the channel's value at pixel 0 (a pilot of its mean: no cancellation when |mean| >> sigma)
   const half8_t k8 = *reinterpret_cast<const half8_t*>(xb);
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   for (int p = r; p < HW; p += 32) {
-    const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * C);
+    const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * ldx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float f = (float)v[e] - (float)k8[e];
@@ -325,14 +333,14 @@ __global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __res
       c2 += sq[rr][threadIdx.x];
     }
     const float mu = a / (float)HW;                     // mean of x - k
-    mean_s[threadIdx.x] = (float)x[(size_t)b * HW * C + blockIdx.x * 64 + threadIdx.x] + mu;
+    mean_s[threadIdx.x] = (float)x[(size_t)b * HW * ldx + blockIdx.x * 64 + threadIdx.x] + mu;
     rstd_s[threadIdx.x] = rsqrtf(fmaxf(c2 / (float)HW - mu * mu, 0.f) + eps);
   }
   __syncthreads();
   const half_t* gbb = gb + (size_t)b * HW * 2 * C + c0;
   half_t* yb = y + (size_t)b * HW * C + c0;
   for (int p = r; p < HW; p += 32) {
-    const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * C);
+    const half8_t v = *reinterpret_cast<const half8_t*>(xb + (size_t)p * ldx);
     const half8_t ga = *reinterpret_cast<const half8_t*>(gbb + (size_t)p * 2 * C);
     const half8_t be = *reinterpret_cast<const half8_t*>(gbb + (size_t)p * 2 * C + C);
     half8_t o;
@@ -345,12 +353,17 @@ __global__ __launch_bounds__(256) void instnorm_spade_kernel(const half_t* __res
   }
 }
 
-extern "C" int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void* y, int B, int HW, int C, float eps, void* stream) {
+extern "C" int md_instnorm_spade_ld_f16(const void* x, int ldx, const void* gamma_beta, void* y, int B, int HW, int C, float eps, void* stream) {
   MD_CHECK_ARG(C % 64 == 0, "md_instnorm_spade: C=%d must be a multiple of 64", C);
+  MD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "md_instnorm_spade: ldx=%d must be a multiple of 8 and >= C=%d", ldx, C);
   hipLaunchKernelGGL(instnorm_spade_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)gamma_beta, (half_t*)y, HW,
-                     C, eps);
+                     C, ldx, eps);
   MD_CHECK_LAUNCH("md_instnorm_spade");
   return MD_OK;
+}
+
+extern "C" int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void* y, int B, int HW, int C, float eps, void* stream) {
+  return md_instnorm_spade_ld_f16(x, C, gamma_beta, y, B, HW, C, eps, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ row softmax

@@ -33,6 +33,23 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
+def _pixel_pitch(x, name):
+    """x: (B, H, W, C) or (B, HW, C) fp16 NHWC, contiguous or a channel slice of a wider contiguous NHWC tensor (a skip connection
+    living inside the concat buffer of the up-block resnet that will consume it).  Returns the pixel pitch in elements."""
+    _chk(x, name)
+    C = x.shape[-1]
+    ld = x.stride(-2)
+    ok = x.stride(-1) == 1 and ld >= C and ld % 8 == 0 and x.data_ptr() % 16 == 0
+    n = 1
+    for d in range(x.dim() - 2, -1, -1):                       # every outer dimension walks whole pixels: one uniform pitch
+        ok = ok and (x.shape[d] == 1 or x.stride(d) == ld * n)
+        n *= x.shape[d]
+    if not ok:
+        raise _lib.MdanceHipError(f"{name} must be NHWC with one uniform pixel pitch (contiguous, or a channel slice of a contiguous tensor): "
+                                  f"shape {tuple(x.shape)} strides {tuple(x.stride())}")
+    return ld
+
+
 def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, transpose_out=False, out=None,
          ldc_t=None):
     """out[M, N] = epi(a[M, K] @ w[N, K]^T).  transpose_out: out is [N, ldc_t] (V^T for attention)."""
@@ -58,31 +75,31 @@ def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_
 
 
 def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, stride=1, upsample=False,
-            out=None, pad_lo=1):
-    """x: (B, H, W, Cin) NHWC contiguous; w: [Cout, 9*Cin] packed (ky, kx, cin); returns (B, Ho, Wo, Cout).
+            out=None, pad_lo=1, kw=3):
+    """x: (B, H, W, Cin) NHWC (contiguous or a channel slice: see _pixel_pitch); w: [Cout, 3*kw*Cin] packed (ky, kx, cin);
+    returns (B, Ho, Wo, Cout).
     pad_lo=0 (stride 2 only): zero padding (0,1,0,1) instead of 1 all round (the AutoencoderKL downsampler).
+    kw=1: a 3 x 1 filter (taps along H only; Conv3d (3,1,1) of the temporal VAE decoder with H = frames, W = pixels).
     `out` may be a channel slice of a wider NHWC tensor (row pitch = its last-dim stride)."""
-    _chk(x, "x")
     _chk(w, "w")
-    assert x.dim() == 4 and x.is_contiguous()
+    assert x.dim() == 4
+    ldx = _pixel_pitch(x, "x")
     B, H, W, Cin = x.shape
-    assert w.shape == (cout, 9 * Cin) and w.is_contiguous(), (w.shape, cout, Cin)
+    assert w.shape == (cout, 3 * kw * Cin) and w.is_contiguous(), (w.shape, cout, Cin)
     hup, wup = (H * 2, W * 2) if upsample else (H, W)
-    Ho, Wo = (hup + pad_lo - 2) // stride + 1, (wup + pad_lo - 2) // stride + 1
+    Ho, Wo = (hup + pad_lo - 2) // stride + 1, ((wup + pad_lo - 2) // stride + 1 if kw == 3 else W)
     if out is None:
         out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=F16)
-    assert tuple(out.shape) == (B, Ho, Wo, cout) and out.stride(3) == 1 and out.stride(1) == Wo * out.stride(2) \
-        and out.stride(0) == Ho * out.stride(1), "out must be (B, Ho, Wo, cout) with a uniform pixel pitch"
-    ldy = out.stride(2)
-    r2 = residual.view(-1, residual.shape[-1]) if residual is not None else None
+    assert tuple(out.shape) == (B, Ho, Wo, cout), (tuple(out.shape), (B, Ho, Wo, cout))
+    ldy = _pixel_pitch(out, "out")
+    r2 = residual.flatten(0, -2) if residual is not None else None
     ldr = _rowmajor(r2, "residual") if r2 is not None else 0
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
     _chk(bias, "bias")
-    _chk(out, "out")
-    _lib.call("md_conv3x3_pad_nhwc_f16", x.data_ptr(), w.data_ptr(), out.data_ptr(), ldy, B, H, W, Cin, cout, stride,
+    _lib.call("md_conv_nhwc_f16", x.data_ptr(), ldx, w.data_ptr(), out.data_ptr(), ldy, B, H, W, Cin, cout, kw, stride,
               int(upsample), int(pad_lo), _p(bias), _p(r2), ldr, _p(rowadd), ldra, rows_per_group, act, _st(),
-              meta=(f"conv3x3 B={B} {H}x{W} Cin={Cin} Cout={cout} s={stride} up={int(upsample)}",
-                    2.0 * B * Ho * Wo * cout * 9 * Cin, 2.0 * (B * H * W * Cin + cout * 9 * Cin + B * Ho * Wo * cout)))
+              meta=(f"conv3x{kw} B={B} {H}x{W} Cin={Cin} Cout={cout} s={stride} up={int(upsample)}",
+                    2.0 * B * Ho * Wo * cout * 3 * kw * Cin, 2.0 * (B * H * W * Cin + cout * 3 * kw * Cin + B * Ho * Wo * cout)))
     return out
 
 
@@ -90,9 +107,9 @@ _gn_ws = {}
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu=False, out=None):
-    """x: (B, HW, C) or (B, H, W, C) NHWC contiguous."""
-    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
-    assert x.is_contiguous()
+    """x: (B, HW, C) or (B, H, W, C) NHWC, contiguous or a channel slice (see _pixel_pitch); the output is contiguous."""
+    _chk(gamma, "gamma"); _chk(beta, "beta")
+    ldx = _pixel_pitch(x, "x")
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     need = _lib.load().md_groupnorm_workspace_bytes(B, HW, C, groups)
@@ -102,8 +119,9 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, out=None):
         ws = torch.empty((max(need, 1 << 20) + 3) // 4, device=x.device, dtype=torch.float32)
         _gn_ws[key] = ws
     if out is None:
-        out = torch.empty_like(x)
-    _lib.call("md_groupnorm_nhwc_f16", x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, C, groups,
+        out = torch.empty(x.shape, device=x.device, dtype=F16)
+    assert out.is_contiguous() and out.shape == x.shape
+    _lib.call("md_groupnorm_ld_nhwc_f16", x.data_ptr(), ldx, out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, C, groups,
               float(eps), int(silu), ws.data_ptr(), ws.numel() * 4, _st(),
               meta=(f"groupnorm B={B} HW={HW} C={C}", 0.0, 6.0 * B * HW * C))
     return out
@@ -124,12 +142,13 @@ def layernorm(x, gamma, beta, eps=1e-5, add=None, add_mode=0, add_row_begin=0, r
 
 def instnorm_spade(x, gamma_beta, eps=1e-5):
     """x: (B, HW, C); gamma_beta: (B, HW, 2C)."""
-    _chk(x, "x"); _chk(gamma_beta, "gamma_beta")
-    assert x.is_contiguous() and gamma_beta.is_contiguous()
+    _chk(gamma_beta, "gamma_beta")
+    ldx = _pixel_pitch(x, "x")
+    assert gamma_beta.is_contiguous()
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
-    y = torch.empty_like(x)
-    _lib.call("md_instnorm_spade_f16", x.data_ptr(), gamma_beta.data_ptr(), y.data_ptr(), B, HW, C, float(eps), _st())
+    y = torch.empty(x.shape, device=x.device, dtype=F16)
+    _lib.call("md_instnorm_spade_ld_f16", x.data_ptr(), ldx, gamma_beta.data_ptr(), y.data_ptr(), B, HW, C, float(eps), _st())
     return y
 
 

@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle evaluates many SMALL operators (reduced-width UNets, 16 x 16 latents): on the GPU box's 128 hardware threads
+    # ATen's intra-op pool makes them ~7x slower than on 16 (bench.py's thread sweep: 16.5 s vs 2.45 s per configs[0] step; the two
+    # 20 / 30-step window tests took 83 + 116 s on 128 threads).  The oracle's results do not depend on the thread count.
+    import torch
+    torch.set_num_threads(min(torch.get_num_threads(), int(os.environ.get("MD_TEST_THREADS", "16"))))
 
 
 @pytest.fixture(scope="session")
