@@ -62,7 +62,8 @@ class Affine(nn.Module):
 
 
 def tokens(x):
-    return x.view(-1, x.shape[-1])
+    """[pixels, C] view of an NHWC tensor -- also of a channel slice of a wider one (row pitch = the wider tensor's channel count)."""
+    return x.flatten(0, -2)
 
 
 def groupnorm_frames(x, w, b, eps, silu, gn_frames=1):
@@ -100,10 +101,11 @@ class ResnetBlock(_Packed):
             pk["scb"] = packing.vec(self.conv_shortcut.bias, dev)
         return pk
 
-    def forward(self, x, temb, rows_per_group, gn_frames=1):
+    def forward(self, x, temb, rows_per_group, gn_frames=1, out=None):
         """x (B,H,W,cin); temb [groups, cout] = time_emb_proj(silu(emb)) rows (already projected, see TimeEmbedding).
         gn_frames > 1: GroupNorm statistics run over that many consecutive frames (the reference's plain nn.GroupNorm on
-        the 5-D tensor when use_inflated_groupnorm=False, src/models/resnet.py:156-191); 1 = per frame (InflatedGroupNorm)."""
+        the 5-D tensor when use_inflated_groupnorm=False, src/models/resnet.py:156-191); 1 = per frame (InflatedGroupNorm).
+        x may be a channel slice of a wider NHWC tensor and `out` (B,H,W,cout) another one: see _UNetBase._skip_plan."""
         pk = self.packed()
         h = groupnorm_frames(x, pk["n1w"], pk["n1b"], self.eps, True, gn_frames)
         h = ops.conv3x3(h, pk["c1"], self.cout, bias=pk["c1b"], rowadd=temb, rows_per_group=rows_per_group)
@@ -112,7 +114,7 @@ class ResnetBlock(_Packed):
             sc = ops.gemm(tokens(x), pk["sc"], bias=pk["scb"]).view(x.shape[:-1] + (self.cout,))
         else:
             sc = x
-        return ops.conv3x3(h, pk["c2"], self.cout, bias=pk["c2b"], residual=sc)
+        return ops.conv3x3(h, pk["c2"], self.cout, bias=pk["c2b"], residual=sc, out=out)
 
 
 class ConvSampler(_Packed):
@@ -127,17 +129,17 @@ class ConvSampler(_Packed):
     def _pack(self, dev):
         return dict(w=packing.conv3x3_weight(self.conv.weight, dev), b=packing.vec(self.conv.bias, dev))
 
-    def forward(self, x, size=None):
+    def forward(self, x, size=None, out=None):
         """size=(h, w): forced nearest-resize target (the reference's `upsample_size` for latents that are not a multiple of
         2**levels, src/models/unet_3d_mix.py:447-455,564-586); the exact 2x case stays folded into the conv's addressing."""
         pk = self.packed()
         if self.up:
             B, H, W, C = x.shape
             if size is not None and tuple(size) != (2 * H, 2 * W):
-                x = ops.pack_nhwc(x, B, 1, (H * W * C, 0, 1, W * C, C), 0, C, C, size[0], size[1], hin=H, win=W)
-                return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"])
-            return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], upsample=True)
-        return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], stride=2)
+                x = ops.pack_nhwc(x, B, 1, (x.stride(0), 0, 1, x.stride(1), x.stride(2)), 0, C, C, size[0], size[1], hin=H, win=W)
+                return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], out=out)
+            return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], upsample=True, out=out)
+        return ops.conv3x3(x, pk["w"], self.c, bias=pk["b"], stride=2, out=out)
 
 
 # ------------------------------------------------------------------------------------------------ attention / FF
@@ -306,7 +308,7 @@ class SpatialTransformer(_Packed):
                     pi=packing.conv1x1_weight(self.proj_in.weight, dev), pib=packing.vec(self.proj_in.bias, dev),
                     po=packing.conv1x1_weight(self.proj_out.weight, dev), pob=packing.vec(self.proj_out.bias, dev))
 
-    def forward(self, x, cross):
+    def forward(self, x, cross, out=None):
         pk = self.packed()
         B, Hh, Ww, C = x.shape
         blk = self.transformer_blocks[0]
@@ -315,6 +317,9 @@ class SpatialTransformer(_Packed):
         h = blk(h, B, Hh * Ww, cross)
         if blk.ref_mode == "write" and blk.stop_after_bank:
             return x
+        if out is not None:
+            ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x), out=tokens(out))
+            return out
         return ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x)).view(x.shape)
 
 
@@ -386,7 +391,7 @@ class MotionModule(_Packed):
         _pack_ff(tb.ff, dev, pk)
         return pk
 
-    def forward(self, x, nb, f):
+    def forward(self, x, nb, f, out=None):
         """x: (nb*f, H, W, C), frames of one clip-half contiguous."""
         pk = self.packed()
         if f > self.max_len:
@@ -405,6 +410,9 @@ class MotionModule(_Packed):
             h = ops.gemm(a, pk[f"o{i}"], bias=pk[f"o{i}b"], residual=h)
         n = ops.layernorm(h, pk["fnw"], pk["fnb"])
         h = _run_ff(pk, n, h)
+        if out is not None:
+            ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x), out=tokens(out))
+            return out
         return ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x)).view(x.shape)
 
 

@@ -14,7 +14,7 @@ from torch import nn
 
 from . import ops
 from .blocks import MANModule
-from .unet_3d_mix import _Config, _UNetBase
+from .unet_3d_mix import _Config, _Skips, _UNetBase
 
 
 @dataclass
@@ -133,27 +133,31 @@ class UNet2DConditionModel(_UNet2DBase):
         last_writer = self.up_blocks[-1].attentions[-1].transformer_blocks[0] \
             if blocks and all(b.ref_mode == "write" for b in blocks) else None
         # the sample after the LAST bank write is discarded by the pipeline: skip that dead tail (result preserving)
-        x = ops.conv3x3(x, pk["cin"], self.conv_in.weight.shape[0], bias=pk["cinb"])
-        skips = [x]
+        c0 = self.conv_in.weight.shape[0]
+        skips = _Skips(self._skip_plan())                                    # skips are born inside their concat buffers
+        x = ops.conv3x3(x, pk["cin"], c0, bias=pk["cinb"], out=skips.slot(B, hh, ww, c0, dev))
         for i, blk in enumerate(self.down_blocks):
             for j, r in enumerate(blk.resnets):
-                x = r(x, self._temb(pk, trows, r), fpg * x.shape[1] * x.shape[2])
+                H_, W_ = x.shape[1:3]
+                dst = skips.slot(B, H_, W_, r.cout, dev)
+                x = r(x, self._temb(pk, trows, r), fpg * H_ * W_, out=None if blk.has_cross_attention else dst)
                 if blk.has_cross_attention:
-                    x = blk.attentions[j](x, cross)
-                skips.append(x)
+                    x = blk.attentions[j](x, cross, out=dst)
             if blk.downsamplers is not None:
-                x = blk.downsamplers[0](x)
-                skips.append(x)
-            # MAN after the skips were captured (quirk 10, src/models/unet_2d_mix.py:1272-1289)
+                x = blk.downsamplers[0](x, out=skips.slot(B, (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, blk.downsamplers[0].c, dev))
+            # MAN after the skips were captured (quirk 10, src/models/unet_2d_mix.py:1272-1289): reads the skip slice, writes a fresh tensor
             x = self.man_blocks[i](x, motion_at(x.shape[1], x.shape[2]))
         mb = self.mid_block
         x = mb.resnets[0](x, self._temb(pk, trows, mb.resnets[0]), fpg * x.shape[1] * x.shape[2])
         x = mb.attentions[0](x, cross)
-        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), fpg * x.shape[1] * x.shape[2])
+        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), fpg * x.shape[1] * x.shape[2], out=skips.hidden_slot())
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
-                x = ops.concat_channels(x, skips.pop())
-                x = r(x, self._temb(pk, trows, r), fpg * x.shape[1] * x.shape[2])
+                x = skips.pop(x)                                             # [hidden | skip]: nothing is copied
+                H_, W_ = x.shape[1:3]
+                last = j == len(blk.resnets) - 1
+                dst = skips.hidden_slot() if len(skips) and not (last and blk.upsamplers is not None) else None
+                x = r(x, self._temb(pk, trows, r), fpg * H_ * W_, out=None if blk.has_cross_attention else dst)
                 if blk.has_cross_attention:
                     tb = blk.attentions[j].transformer_blocks[0]
                     if self.skip_dead_tail and tb is last_writer:
@@ -163,9 +167,9 @@ class UNet2DConditionModel(_UNet2DBase):
                         finally:
                             tb.stop_after_bank = False
                         return None
-                    x = blk.attentions[j](x, cross)
+                    x = blk.attentions[j](x, cross, out=dst)
             if blk.upsamplers is not None:
-                x = blk.upsamplers[0](x, skips[-1].shape[1:3] if force_size else None)
+                x = blk.upsamplers[0](x, skips.top_hw() if force_size else None, out=skips.hidden_slot())
         return x
 
     skip_dead_tail = False

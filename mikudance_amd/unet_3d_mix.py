@@ -70,6 +70,38 @@ class _MidBlock(nn.Module):
             self.motion_modules = nn.ModuleList([MotionModule(c, **mm_kwargs)]) if motion else [None]
 
 
+class _Skips:
+    """Bookkeeping of the concat buffers during one forward (see _UNetBase._skip_plan)."""
+
+    def __init__(self, plan):
+        self.plan, self.k, self.stack = plan, 0, []
+
+    def slot(self, B, H, W, cs, device):
+        """Destination of the next skip tensor to be produced: the right-hand channel slice of a fresh concat buffer."""
+        c1 = self.plan[self.k]
+        self.k += 1
+        buf = torch.empty((B, H, W, c1 + cs), device=device, dtype=torch.float16)
+        self.stack.append((buf, c1))
+        return buf[..., c1:]
+
+    def hidden_slot(self):
+        """Where the up path writes the hidden state that meets the top skip: the left-hand slice of that skip's buffer."""
+        buf, c1 = self.stack[-1]
+        return buf[..., :c1]
+
+    def top_hw(self):
+        return self.stack[-1][0].shape[1:3]
+
+    def pop(self, x):
+        """The concatenated [hidden | skip] tensor; `x` must be the hidden slice written through hidden_slot()."""
+        buf, c1 = self.stack.pop()
+        assert x.data_ptr() == buf.data_ptr() and x.shape[-1] == c1 and x.shape[:3] == buf.shape[:3], "hidden state was not produced in place"
+        return buf
+
+    def __len__(self):
+        return len(self.stack)
+
+
 class _UNetBase(_Packed):
     """Shared skeleton of the two UNets (block layout of SD-1.5: 3 cross-attn levels + 1 plain level)."""
 
@@ -108,6 +140,24 @@ class _UNetBase(_Packed):
 
     def _register_extra(self):
         pass
+
+    # -------- skip connections are born inside the concat buffer of the up-block resnet that consumes them
+    def _skip_plan(self):
+        """The reference concatenates [hidden, skip] along the channels in front of every up-block resnet
+        (src/models/unet_3d_blocks.py:736,877; diffusers unet_2d_blocks likewise): a pure copy of 2 x (C1 + Cs) bytes per element.
+        Here the k-th skip tensor (production order: conv_in, every down layer, every downsampler) is WRITTEN by its producer
+        into the right-hand Cs channels of a (B, H, W, C1 + Cs) buffer, the up path later writes its C1 hidden channels into the
+        left part, and the resnet reads the buffer as it is.  Down-path consumers of a skip tensor read the channel slice
+        (pixel pitch C1 + Cs).  Returns C1 for every skip in production order."""
+        ups = [r for blk in self.up_blocks for r in blk.resnets]
+        cs = [self.conv_in.weight.shape[0]]
+        for blk in self.down_blocks:
+            cs += [r.cout for r in blk.resnets]
+            if blk.downsamplers is not None:
+                cs.append(blk.downsamplers[0].c)
+        assert len(cs) == len(ups), (len(cs), len(ups))
+        return [ups[len(ups) - 1 - k].cin - c for k, c in enumerate(cs)]
+
 
     # -------- packed top-level weights: conv_in (Cin zero-padded to 64), time embedding, all time_emb_proj fused
     def _resnets(self):
@@ -266,35 +316,43 @@ class UNet3DConditionModel(_UNetBase):
         force_size = self._needs_upsample_size(hh, ww, len(self.down_blocks))
         trows = self._time_rows(pk, timesteps, dev)                         # [nb, sumC]
         gf = 1 if self.use_inflated_groupnorm else f                        # plain nn.GroupNorm on 5-D: stats across frames
-        x = ops.conv3x3(x, pk["cin"], self.conv_in.weight.shape[0], bias=pk["cinb"])
-        skips = [x]
+        B = x.shape[0]
+        c0 = self.conv_in.weight.shape[0]
+        skips = _Skips(self._skip_plan())
+        x = ops.conv3x3(x, pk["cin"], c0, bias=pk["cinb"], out=skips.slot(B, hh, ww, c0, dev))
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
-                x = r(x, self._temb(pk, trows, r), f * x.shape[1] * x.shape[2], gf)
+                H_, W_ = x.shape[1:3]
+                mm = blk.motion_modules[j]
+                dst = skips.slot(B, H_, W_, r.cout, dev)                 # the layer's LAST operator writes the skip in place
+                x = r(x, self._temb(pk, trows, r), f * H_ * W_, gf, out=None if (blk.has_cross_attention or mm is not None) else dst)
                 if blk.has_cross_attention:
-                    x = blk.attentions[j](x, cross)
-                if blk.motion_modules[j] is not None:
-                    x = blk.motion_modules[j](x, nb, f)
-                skips.append(x)
+                    x = blk.attentions[j](x, cross, out=None if mm is not None else dst)
+                if mm is not None:
+                    x = mm(x, nb, f, out=dst)
             if blk.downsamplers is not None:
-                x = blk.downsamplers[0](x)
-                skips.append(x)
+                x = blk.downsamplers[0](x, out=skips.slot(B, (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, blk.downsamplers[0].c, dev))
         mb = self.mid_block
         x = mb.resnets[0](x, self._temb(pk, trows, mb.resnets[0]), f * x.shape[1] * x.shape[2], gf)
         x = mb.attentions[0](x, cross)
         if mb.motion_modules[0] is not None:
             x = mb.motion_modules[0](x, nb, f)
-        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), f * x.shape[1] * x.shape[2], gf)
+        x = mb.resnets[1](x, self._temb(pk, trows, mb.resnets[1]), f * x.shape[1] * x.shape[2], gf, out=skips.hidden_slot())
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
-                x = ops.concat_channels(x, skips.pop())
-                x = r(x, self._temb(pk, trows, r), f * x.shape[1] * x.shape[2], gf)
+                x = skips.pop(x)                                         # [hidden | skip]: nothing is copied
+                H_, W_ = x.shape[1:3]
+                mm = blk.motion_modules[j]
+                last = j == len(blk.resnets) - 1
+                # the layer's last operator writes the next resnet's hidden slice -- unless an upsampler comes first (it does then)
+                dst = skips.hidden_slot() if len(skips) and not (last and blk.upsamplers is not None) else None
+                x = r(x, self._temb(pk, trows, r), f * H_ * W_, gf, out=None if (blk.has_cross_attention or mm is not None) else dst)
                 if blk.has_cross_attention:
-                    x = blk.attentions[j](x, cross)
-                if blk.motion_modules[j] is not None:
-                    x = blk.motion_modules[j](x, nb, f)
+                    x = blk.attentions[j](x, cross, out=None if mm is not None else dst)
+                if mm is not None:
+                    x = mm(x, nb, f, out=dst)
             if blk.upsamplers is not None:
-                x = blk.upsamplers[0](x, skips[-1].shape[1:3] if force_size else None)
+                x = blk.upsamplers[0](x, skips.top_hw() if force_size else None, out=skips.hidden_slot())
         x = groupnorm_frames(x, pk["ow"], pk["ob"], self.norm_eps, True, gf)
         return tokens(ops.conv3x3(x, pk["co"], 4, bias=pk["cob"]))
 

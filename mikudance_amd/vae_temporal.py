@@ -12,9 +12,9 @@ and decodes latents in chunks of 16 frames with `vae.decode(chunk, num_frames=le
     decoder.conv_norm_out, decoder.conv_out, decoder.time_conv_out        (temporal convs: Conv3d weights [Cout, Cin, 3, 1, 1])
 
 Temporal pieces on the existing kernels, no new ones:
-  * Conv3d (3,1,1), padding (1,0,0) over a clip = three token GEMMs on frame-shifted row ranges of the NHWC tensor (frames of a
-    clip are contiguous): out = W[:,:,1] x_t + b;  out[frames 1..] += W[:,:,0] x_{t-1};  out[frames ..f-2] += W[:,:,2] x_{t+1}
-    (in-place residual epilogue of md_gemm_f16) -- no im2col copy;
+  * Conv3d (3,1,1), padding (1,0,0) over a clip = ONE implicit GEMM (K = 3 C): on the (clips, frames, h*w, C) view it is a 3 x 1
+    filter over an image whose rows are the frames (md_conv_nhwc_f16, kw = 1; frames of a clip are contiguous) -- no im2col copy,
+    one rounding like the reference's Conv3d;
   * GroupNorm of the temporal ResNet runs over (frames, h, w) per group = md_groupnorm_nhwc_f16 on the (clip, f*h*w, C) view;
   * AlphaBlender(merge_strategy="learned", switch_spatial_to_temporal_mix=True): out = (1 - s) x_spatial + s x_temporal with
     s = sigmoid(mix_factor) and x_temporal = x_spatial + h, i.e. x_spatial + s h: folded into the second temporal conv (weights
@@ -44,17 +44,29 @@ class _Conv3dT(nn.Module):
 
 
 def _temporal_conv(x, w3, bias, frames, residual=None):
-    """x: (B, H, W, C) fp16 with B = clips * frames, frames of a clip contiguous; w3 = [W_prev, W_mid, W_next] each [Cout][C]."""
+    """nn.Conv3d(C, Cout, (3, 1, 1), padding (1, 0, 0)) over clips of `frames` frames.  x: (B, H, W, C) fp16 with B = clips * frames,
+    frames of a clip contiguous; w3: [Cout][3 taps (prev, this, next frame)][C].
+
+    On the (clips, frames, H*W, C) view the temporal convolution IS a 3 x 1 filter over an image whose rows are the frames:
+    md_conv_nhwc_f16 with kw = 1 -- one implicit GEMM with K = 3 C, the three taps summed in the fp32 accumulator and rounded
+    ONCE like the reference's Conv3d (three accumulating token GEMMs, the form used until round 3, rounded the partial sums to
+    fp16 twice more).  Clips beyond the kernel's 2^24-pixel image limit fall back to that form."""
     B, H, W, C = x.shape
     hw = H * W
+    cout = w3.shape[0]
+    if frames * hw < (1 << 24):
+        out = ops.conv3x3(x.view(B // frames, frames, hw, C), w3, cout, bias=bias, kw=1,
+                          residual=tokens(residual) if residual is not None else None)
+        return out.view(B, H, W, cout)
+    taps = [w3.view(cout, 3, C)[:, t].contiguous() for t in range(3)]
     xt = tokens(x)
-    out = ops.gemm(xt, w3[1], bias=bias, residual=tokens(residual) if residual is not None else None)
+    out = ops.gemm(xt, taps[1], bias=bias, residual=tokens(residual) if residual is not None else None)
     if frames > 1:
         for c0 in range(0, B, frames):                                   # per clip: frame t gets x_{t-1} and x_{t+1}
             lo, hi = c0 * hw, (c0 + frames) * hw
             o_late, o_early = out[lo + hw:hi], out[lo:hi - hw]
-            ops.gemm(xt[lo:hi - hw], w3[0], residual=o_late, out=o_late)
-            ops.gemm(xt[lo + hw:hi], w3[2], residual=o_early, out=o_early)
+            ops.gemm(xt[lo:hi - hw], taps[0], residual=o_late, out=o_late)
+            ops.gemm(xt[lo + hw:hi], taps[2], residual=o_early, out=o_early)
     return out.view(B, H, W, -1)
 
 
@@ -72,7 +84,8 @@ class TemporalResnet(_Packed):
         b = conv.bias.detach().to(dev, torch.float32)
         if scale is not None:
             w, b = w * scale, b * scale
-        return [w[:, :, t].to(torch.float16).contiguous() for t in range(3)], b.to(torch.float16).contiguous()
+        # [Cout][tap][Cin]: K runs over (frame tap, channel), the layout of a 3 x 1 filter for md_conv_nhwc_f16(kw = 1)
+        return w.permute(0, 2, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous(), b.to(torch.float16).contiguous()
 
     def _pack(self, dev):
         V = packing.vec

@@ -40,7 +40,9 @@ d = lambda t: t.to(dev)
 for M, N, K in [(256, 320, 128), (1000, 320, 192), (77, 640, 256), (2048, 320, 320), (700, 1280, 1280), (4096, 640, 2880),
                 (57600, 320, 256), (100000, 320, 192), (20000, 1280, 128),
                 # N % 256 == 0 only: the 192 x 256 tile (14 DMA pieces per wave and K tile instead of 16)
-                (256, 256, 128), (1000, 512, 192), (77, 768, 256), (3000, 1024, 1280), (57600, 256, 256), (30000, 1280, 320)]:
+                (256, 256, 128), (1000, 512, 192), (77, 768, 256), (3000, 1024, 1280), (57600, 256, 256), (30000, 1280, 320),
+                # N % 128 == 0 only: the 256 x 128 tile (wave tile 128 x 64; the 128-channel layers of the AutoencoderKL)
+                (300, 128, 128), (5000, 384, 256), (70000, 128, 1152)]:
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     check(f"gemm {M}x{N}x{K}", lambda: ops.gemm(d(a), d(w)), a.float() @ w.float().t())
 
@@ -103,6 +105,34 @@ for cin, cout, h, wd, stride, up in [(64, 320, 8, 8, 1, False), (320, 320, 24, 2
     xn = x.permute(0, 2, 3, 1).contiguous()
     wpk = packing.conv3x3_weight(wt, dev)
     check(f"conv {cin}->{cout} {h}x{wd} s{stride} up{int(up)}", lambda: ops.conv3x3(d(xn), wpk, cout, bias=d(bias), stride=stride, upsample=up), ref)
+# Cout % 128 == 0 only (256 x 128 tile), input a CHANNEL SLICE of a wider NHWC tensor (a skip connection inside its concat buffer:
+# pixel pitch ldx > Cin), output into a channel slice of another one
+for cin, cout, h, wd, stride, up, B in [(128, 128, 64, 64, 1, False, 9), (64, 128, 9, 7, 2, False, 3), (128, 384, 12, 12, 1, True, 3),
+                                        (320, 320, 24, 24, 1, False, 3), (128, 640, 48, 48, 1, False, 8)]:
+    wide = rnd(B, h, wd, cin + 192, seed=40)
+    xs = d(wide)[..., 192:]
+    wt = rnd(cout, cin, 3, 3, seed=41, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=42)
+    xin = wide[..., 192:].float().permute(0, 3, 1, 2)
+    xin = F.interpolate(xin, scale_factor=2.0, mode="nearest") if up else xin
+    ref = F.conv2d(xin, wt.float(), bias.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    wpk = packing.conv3x3_weight(wt, dev)
+    check(f"conv slice-in {cin}->{cout} {h}x{wd} s{stride} up{int(up)}", lambda: ops.conv3x3(xs, wpk, cout, bias=d(bias), stride=stride, upsample=up), ref)
+    big = torch.full(tuple(ref.shape[:3]) + (cout + 64,), 7.0, dtype=torch.float16, device=dev)
+    ops.conv3x3(xs, wpk, cout, bias=d(bias), stride=stride, upsample=up, out=big[..., 64:])
+    check(f"conv slice-out {cin}->{cout}", lambda: big[..., 64:], ref)
+    assert float((big[..., :64].float() - 7.0).abs().max()) == 0.0, "wrote outside the output slice"
+
+# 3 x 1 filters (kw = 1): nn.Conv3d(C, Cout, (3, 1, 1), padding (1, 0, 0)) on the (clips, frames, h*w, C) view
+for clips, frames, hw, c, cout in [(2, 5, 96, 128, 128), (1, 16, 4096, 128, 128), (3, 4, 100, 256, 256), (2, 1, 64, 64, 320), (1, 16, 1024, 512, 512)]:
+    x = rnd(clips, frames, hw, c, seed=50)
+    w3 = rnd(cout, c, 3, seed=51, scale=(3 * c) ** -0.5)
+    bias, res = rnd(cout, seed=52), rnd(clips * frames * hw, cout, seed=53)
+    ref = F.conv3d(x.float().permute(0, 3, 1, 2)[..., None], w3.float()[..., None, None], bias.float(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1)
+    wpk = d(w3.permute(0, 2, 1).reshape(cout, 3 * c).contiguous())
+    check(f"conv3x1 {clips}x{frames}x{hw} {c}->{cout}", lambda: ops.conv3x3(d(x), wpk, cout, bias=d(bias), kw=1), ref)
+    check(f"conv3x1 + residual", lambda: ops.conv3x3(d(x), wpk, cout, bias=d(bias), kw=1, residual=d(res)), ref + res.float().view(ref.shape))
+
 B, c, h, wd = 4, 320, 8, 8
 x, wt, bias = rnd(B, h, wd, c, seed=23), rnd(c, c, 3, 3, seed=24, scale=(9 * c) ** -0.5), rnd(c, seed=25)
 temb, res = rnd(2, c, seed=26), rnd(B, h, wd, c, seed=27)

@@ -525,3 +525,75 @@ def test_conv3x3_rejects_images_beyond_the_24_bit_tap_arithmetic(dev):
     with pytest.raises(MdanceHipError, match="2\\^24"):
         call("md_conv3x3_nhwc_f16", x.data_ptr(), w.data_ptr(), y.data_ptr(), 64, 1, 4096, 4096, 64, 64, 1, 0, 0, 0, 0, 0, 0, 0, 0,
              torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------------------------- channel slices, 3 x 1 taps (round 4)
+@pytest.mark.parametrize("B,H,W,C,lead,tail,silu", [(2, 8, 8, 64, 64, 0, True), (3, 10, 7, 320, 640, 0, False), (32, 96, 96, 320, 320, 0, True),
+                                                   (2, 24, 24, 640, 1280, 64, True), (2, 12, 12, 1280, 0, 1280, False)])
+def test_groupnorm_on_a_channel_slice(dev, B, H, W, C, lead, tail, silu):
+    """x = wide[..., lead:lead+C]: a skip connection living inside the concat buffer of the up-block resnet that consumes it
+    (pixel pitch lead + C + tail); the result must equal GroupNorm of the contiguous copy bit for bit."""
+    wide = rnd(B, H, W, lead + C + tail, seed=60).to(dev)
+    wide = wide + 3.0 * torch.arange(lead + C + tail, device=dev).remainder(7).half()        # per-channel offsets: group means differ
+    x = wide[..., lead:lead + C]
+    g, b = (1 + 0.1 * rnd(C, seed=61)).to(dev), rnd(C, seed=62).to(dev)
+    ref = F.group_norm(x.float().cpu().permute(0, 3, 1, 2), 32, g.float().cpu(), b.float().cpu(), 1e-5).permute(0, 2, 3, 1)
+    ref = F.silu(ref) if silu else ref
+    got = ops.groupnorm(x, g, b, 32, 1e-5, silu=silu)
+    assert got.is_contiguous() and got.shape == x.shape
+    close(got, ref, what="groupnorm slice")
+    assert torch.equal(got, ops.groupnorm(x.contiguous(), g, b, 32, 1e-5, silu=silu))
+    with pytest.raises(Exception):
+        ops.groupnorm(wide[..., 4:4 + C] if lead + tail >= 4 else x[:, :, ::2], g, b, 32, 1e-5)   # unaligned slice / non-uniform pitch
+
+
+def test_instnorm_spade_on_a_channel_slice(dev):
+    B, HW, C = 3, 150, 128
+    wide = rnd(B, HW, C + 192, seed=63).to(dev)
+    gb = rnd(B, HW, 2 * C, seed=64).to(dev)
+    x = wide[..., 192:]
+    assert torch.equal(ops.instnorm_spade(x, gb), ops.instnorm_spade(x.contiguous(), gb))
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,up", [(64, 64, 8, 8, 1, False), (128, 192, 12, 12, 2, False), (64, 4, 10, 10, 1, False),
+                                                    (64, 320, 5, 6, 1, True)])
+def test_conv3x3_on_a_channel_slice_small_tile_kernels(dev, cin, cout, h, w, stride, up):
+    """The occupancy flavours of gemm_kernel (small problems) with an input pixel pitch > Cin; the persistent kernels are covered by
+    tests/gemm_sp_check.py."""
+    B = 2
+    wide = rnd(B, h, w, cin + 320, seed=70)
+    wt, bias = rnd(cout, cin, 3, 3, seed=71, scale=(9 * cin) ** -0.5), rnd(cout, seed=72)
+    xin = wide[..., 320:].float().permute(0, 3, 1, 2)
+    xin = F.interpolate(xin, scale_factor=2.0, mode="nearest") if up else xin
+    ref = F.conv2d(xin, wt.float(), bias.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    got = ops.conv3x3(wide.to(dev)[..., 320:], packing.conv3x3_weight(wt, dev), cout, bias=bias.to(dev), stride=stride, upsample=up)
+    close(got, ref, what="conv slice")
+
+
+@pytest.mark.parametrize("clips,frames,hw,c,cout", [(2, 3, 20, 64, 64), (1, 4, 33, 128, 192), (2, 1, 16, 64, 64)])
+def test_conv3x1_temporal_taps_small_tile_kernels(dev, clips, frames, hw, c, cout):
+    """kw = 1: nn.Conv3d(C, Cout, (3,1,1), padding (1,0,0)) over the frames of each clip as ONE implicit GEMM (K = 3 C)."""
+    x = rnd(clips, frames, hw, c, seed=80)
+    w3, bias = rnd(cout, c, 3, seed=81, scale=(3 * c) ** -0.5), rnd(cout, seed=82)
+    ref = F.conv3d(x.float().permute(0, 3, 1, 2)[..., None], w3.float()[..., None, None], bias.float(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1)
+    wpk = w3.permute(0, 2, 1).reshape(cout, 3 * c).contiguous().to(dev)
+    close(ops.conv3x3(x.to(dev), wpk, cout, bias=bias.to(dev), kw=1), ref, what="conv3x1")
+
+
+def test_eta_ddim_kernel(dev):
+    """md_cfg_ddim_step_eta against the formula of diffusers DDIMScheduler.step (restated in oracle.DDIM.step)."""
+    Ft, HW = 3, 50
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(Ft, HW, 4, generator=g).half()
+    ns = torch.randn(2, Ft, HW, 4, generator=g)
+    cnt = torch.tensor([1.0, 2.0, 3.0])
+    z = torch.randn(Ft, HW, 4, generator=g).half()
+    a_t, a_prev, eta, gs = 0.31, 0.47, 0.8, 3.5
+    u, c = (ns / cnt.view(1, -1, 1, 1)).unbind(0)
+    v = u + gs * (c - u)
+    x = lat.float()
+    std = eta * ((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)) ** 0.5
+    want = a_prev ** 0.5 * (a_t ** 0.5 * x - (1 - a_t) ** 0.5 * v) + (1 - a_prev - std ** 2) ** 0.5 * (a_t ** 0.5 * v + (1 - a_t) ** 0.5 * x) + std * z.float()
+    l = lat.to(dev).clone()
+    ops.cfg_ddim_step(l, ns.to(dev), cnt.to(dev), Ft, HW, gs, a_t, a_prev, eta=eta, variance_noise=z.to(dev))
+    close(l, want, rtol=2e-3, what="ddim eta")
