@@ -119,3 +119,57 @@ def test_temporal_decoder_vs_oracle(chans, frames, clips):
     assert rel_l2(m.float(), O.vae_encode_moments(sd, x)[:, :4]) < 3e-2
     with pytest.raises(ValueError):
         vae.decode(z[:frames * clips - 1].cuda().half(), num_frames=frames) if frames > 1 else vae.decode(z[:, :3].cuda().half())
+
+
+def _oracle_on_gpu(fn, sd, *args):
+    """The oracle (fp32) evaluated through PyTorch-ROCm on the GPU: the sizes below are minutes of CPU time.  MIOpen is switched
+    off (PyTorch's own im2col / dilated-3d convolutions on rocBLAS: exact fp32, no per-shape kernel search on a fresh box)."""
+    dev = torch.device("cuda:0")
+    sdg = {k: v.to(dev) for k, v in sd.items()}
+    with torch.no_grad():
+        try:
+            with torch.backends.cudnn.flags(enabled=False):
+                out = fn(sdg, *[a.to(dev) if torch.is_tensor(a) else a for a in args])
+        except RuntimeError:
+            out = fn(sdg, *[a.to(dev) if torch.is_tensor(a) else a for a in args])
+    return out.float().cpu()
+
+
+def test_autoencoder_kl_at_768x768_vs_oracle():
+    """SURVEY 8f-1 at the size the pipeline runs it (src/pipelines/pipeline_mikudance.py:115-130,456-549): sd-vae-ft-mse geometry
+    (128, 256, 512, 512), 768 x 768 images / 96 x 96 latents, two images per call.  At this size the 128- and 256-channel layers run on
+    the persistent kernels (256 x 128 and 192 x 256 tiles), the mid-block attention is a 9216 x 9216 single-head softmax."""
+    vae, sd = _vae((128, 256, 512, 512), seed=77)
+    img = (torch.rand(2, 3, 768, 768, generator=torch.Generator().manual_seed(5)) * 2 - 1).half().float()
+    z = torch.randn(2, 4, 96, 96, generator=torch.Generator().manual_seed(6)).half().float()
+    want_m = _oracle_on_gpu(O.vae_encode_moments, sd, img)
+    want_x = _oracle_on_gpu(O.vae_decode, sd, z)
+    got_m = vae.encode(img.cuda().half()).latent_dist.mean
+    r, c = rel_l2(got_m.float(), want_m[:, :4]), cosine(got_m.float(), want_m[:, :4])
+    assert r < 3e-2 and c > 0.999, ("encode", r, c)
+    got_x = vae.decode(z.cuda().half()).sample
+    assert got_x.shape == (2, 3, 768, 768)
+    r, c = rel_l2(got_x.float(), want_x), cosine(got_x.float(), want_x)
+    assert r < 3e-2 and c > 0.999, ("decode", r, c)
+
+
+def test_temporal_decoder_16_frames_at_64x64_latents_vs_oracle():
+    """SURVEY 8f-4 at size: the published geometry (128, 256, 512, 512), ONE clip of 16 frames (the reference's decode_chunk_size,
+    src/pipelines/pipeline_mikudance.py:132-150) at 64 x 64 latents -> 512 x 512 pixels.  Every Conv3d (3,1,1) runs as one 3 x 1
+    implicit GEMM over an image whose rows are the 16 frames (up to 262 144 pixels wide), on the persistent kernels."""
+    from mikudance_amd import AutoencoderKLTemporalDecoder
+    vae = AutoencoderKLTemporalDecoder()
+    shapes = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=31)
+    for k in sd:
+        if k.endswith("mix_factor"):
+            sd[k] = torch.tensor([0.7 if "mid" in k else -0.4])
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.to("cuda", dtype=torch.float16)
+    frames = 16
+    z = torch.randn(frames, 4, 64, 64, generator=torch.Generator().manual_seed(5)).half().float()
+    want = _oracle_on_gpu(O.vae_temporal_decode, sd, z, frames)
+    got = vae.decode(z.cuda().half(), num_frames=frames).sample
+    assert tuple(got.shape) == (frames, 3, 512, 512)
+    r, c = rel_l2(got.float(), want), cosine(got.float(), want)
+    assert r < 3e-2 and c > 0.999, (r, c)

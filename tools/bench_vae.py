@@ -14,7 +14,7 @@ from mikudance_amd import AutoencoderKL, _lib  # noqa: E402
 from mikudance_amd.synth import synth_state_dict  # noqa: E402
 
 dev = torch.device("cuda:0")
-size, frames, batch = int(os.environ.get("MD_VAE_SIZE", "768")), 16, int(os.environ.get("MD_VAE_BATCH", "4"))
+size, frames, batch = int(os.environ.get("MD_VAE_SIZE", "768")), 16, int(os.environ.get("MD_VAE_BATCH", "8"))
 vae = AutoencoderKL()
 vae.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed=77), strict=True)
 vae = vae.half().to(dev).eval()
@@ -51,4 +51,9 @@ for label, d in prof.items():
 res.update(size=size, decodes=frames, encodes=imgs.shape[0], batch=batch,
            families={k: dict(ms=round(v["ms"], 2), tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None)
                      for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])})
+if os.environ.get("MD_VAE_DUMP"):                 # per-shape table of one decode + encode pass (profiles/r04_vae_shapes.txt)
+    with open(os.environ["MD_VAE_DUMP"], "w") as fh:
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            fh.write(f"{v['ms']:10.3f} ms/clip  {v['count']:6d} launches  {(v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['flops'] else 0:8.1f} TF  "
+                     f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:8.1f} GB/s  {k}\n")
 print(json.dumps(res))
