@@ -33,13 +33,14 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
-def _pixel_pitch(x, name):
+def _pixel_pitch(x, name, align=8):
     """x: (B, H, W, C) or (B, HW, C) fp16 NHWC, contiguous or a channel slice of a wider contiguous NHWC tensor (a skip connection
-    living inside the concat buffer of the up-block resnet that will consume it).  Returns the pixel pitch in elements."""
+    living inside the concat buffer of the up-block resnet that will consume it).  Returns the pixel pitch in elements.
+    align: inputs are fetched in 16-byte pieces (pitch and base multiples of 8 elements); outputs (align = 1) may have any pitch."""
     _chk(x, name)
     C = x.shape[-1]
     ld = x.stride(-2)
-    ok = x.stride(-1) == 1 and ld >= C and ld % 8 == 0 and x.data_ptr() % 16 == 0
+    ok = x.stride(-1) == 1 and ld >= C and ld % align == 0 and x.data_ptr() % (2 * align) == 0
     n = 1
     for d in range(x.dim() - 2, -1, -1):                       # every outer dimension walks whole pixels: one uniform pitch
         ok = ok and (x.shape[d] == 1 or x.stride(d) == ld * n)
@@ -91,7 +92,7 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
     if out is None:
         out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=F16)
     assert tuple(out.shape) == (B, Ho, Wo, cout), (tuple(out.shape), (B, Ho, Wo, cout))
-    ldy = _pixel_pitch(out, "out")
+    ldy = _pixel_pitch(out, "out", align=1)
     r2 = residual.flatten(0, -2) if residual is not None else None
     ldr = _rowmajor(r2, "residual") if r2 is not None else 0
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0

@@ -15,10 +15,10 @@ ACT_NONE, ACT_SILU, ACT_RELU, ACT_GEGLU, ACT_QUICKGELU = 0, 1, 2, 3, 4
 CALLS = []          # (name, detail) log, inspected by the tests
 
 
-def _pitch(x):
+def _pitch(x, align=8):
     """The checks of mikudance_amd.ops._pixel_pitch without the device requirement."""
     C, ld = x.shape[-1], x.stride(-2)
-    ok = x.dtype == F16 and x.stride(-1) == 1 and ld >= C and ld % 8 == 0 and x.storage_offset() % 8 == 0
+    ok = x.dtype == F16 and x.stride(-1) == 1 and ld >= C and ld % align == 0 and x.storage_offset() % align == 0
     n = 1
     for d in range(x.dim() - 2, -1, -1):
         ok = ok and (x.shape[d] == 1 or x.stride(d) == ld * n)
@@ -65,7 +65,7 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
     assert x.dim() == 4
     _pitch(x)
     if out is not None:
-        _pitch(out)
+        _pitch(out, align=1)
     B, H, W, Cin = x.shape
     wt = w.float().view(cout, 3, kw, Cin).permute(0, 3, 1, 2)
     xi = x.float().permute(0, 3, 1, 2)
@@ -91,7 +91,8 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
         y = y + residual.float().reshape(B, Ho, Wo, cout)
     CALLS.append(("conv", (tuple(x.shape), tuple(x.stride()), cout, kw, stride, upsample, None if out is None else tuple(out.stride()))))
     if out is None:
-        return y.to(F16).contiguous()
+        out = torch.empty(tuple(y.shape), dtype=F16)       # like the wrapper: allocate, then validate as an output
+        _pitch(out, align=1)
     assert tuple(out.shape) == tuple(y.shape), (out.shape, y.shape)
     out.copy_(y.to(F16))
     return out
