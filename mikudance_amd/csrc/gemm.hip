@@ -27,6 +27,7 @@
 // an output element meet in one lane; written straight from the accumulators (8 % faster than staging).
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GEGLU = 3, ACT_QUICKGELU = 4 };  // 4: x * sigmoid(1.702 x) (CLIP)
@@ -656,8 +657,17 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
     const double c5 = ok5 ? cost(192, 320, 1.56) : 1e30, c4 = ok4 && (force_nt == 0 || force_nt == 4) ? cost(192, 256, 1.28) : 1e30,
                  c2 = ok4 && (force_nt == 0 || force_nt == 2) ? cost(128, 256, 0.95) : 1e30;
     if (c5 < 1e30 || c4 < 1e30 || c2 < 1e30) nt = c5 <= c4 && c5 <= c2 ? 5 : (c4 <= c2 ? 4 : 2);
+    const bool ok128 = sp_eligible<CONV, false, 2>(p);
     // N a multiple of 128 only (the 128-channel convs of the AutoencoderKL at full resolution): the 256 x 128 tile, wave tile 128 x 64
-    else if ((force_nt == 0 || force_nt == 42) && sp_eligible<CONV, false, 2>(p)) nt = 42;
+    const double c42 = ok128 && (force_nt == 0 || force_nt == 42) ? cost(256, 128, 0.95) : 1e30;
+    if (nt == 0 && c42 < 1e30) nt = 42;
+    // 192 x 128 (wave tile 96 x 64, 6 MFMAs per k-step): more and smaller tiles for the launches that cannot fill the chip once with
+    // the larger ones -- the 12 x 12 level: M = 4608, N = 1280 gives 24 x 10 = 240 tiles on 256 CUs where 128 x 256 gives 180.
+    static const double tk32 = env_int("MD_GEMM_SP_TK32", 800) * 1e-3;
+    if (ok128 && (force_nt == 0 || force_nt == 32)) {
+      const double best = std::min(std::min(c5, c42), std::min(c4, c2));
+      if (force_nt == 32 || cost(192, 128, tk32) < best) nt = 32;
+    }
   } else if (!sp_eligible<CONV, true>(p)) {
     nt = 0;
   }
@@ -667,9 +677,10 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
       else if (nt == 4) launch_sp<CONV, false, 4>(p, stream);
       else if (nt == 2) launch_sp<CONV, false, 4, 2>(p, stream);
       else if (nt == 42) launch_sp<CONV, false, 2, 4>(p, stream);
+      else if (nt == 32) launch_sp<CONV, false, 2, 3>(p, stream);
       else launch_sp<CONV, false, 5>(p, stream);
     }
-    return GEGLU ? 144 : (nt == 4 ? 134 : (nt == 2 ? 124 : (nt == 42 ? 142 : 135)));
+    return GEGLU ? 144 : (nt == 4 ? 134 : (nt == 2 ? 124 : (nt == 42 ? 142 : (nt == 32 ? 132 : 135))));
   };
   if (sp == 1 && nt) return run_sp();
   // 1. HBM-bound short-K projections on long token matrices: W-stationary streaming kernel (gemm_ws.h), plain and GEGLU (K = 320)
@@ -693,7 +704,7 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
   //    the 128 x 128 kernel, M = 4608 GEMMs +1..18 %, M = 18 432 x N = 1280 +19..34 %); GEGLU GEMMs with K >= 640 (+24..29 %; at
   //    K = 320 the W-stationary kernel above is 9 % faster)
   if (sp > 0 && nt) {
-    const long tiles = (long)cdiv(p.M, GEGLU || nt == 42 ? 256 : (nt == 2 ? 128 : 192)) * (p.N / (nt == 5 ? 320 : (nt == 42 ? 128 : 256)));
+    const long tiles = (long)cdiv(p.M, GEGLU || nt == 42 ? 256 : (nt == 2 ? 128 : 192)) * (p.N / (nt == 5 ? 320 : (nt == 42 || nt == 32 ? 128 : 256)));
     const bool pick = GEGLU ? p.K >= 640 : (tiles >= 112 && (CONV || p.K >= 640));
     if (pick) return run_sp();
   }

@@ -199,8 +199,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows (6 / 8), W rows (10 / 8)
   // issue schedule of a wave's PA + PB pieces per K tile over the four k-steps that follow the tile's barrier, W pieces first:
   // 6 + 4 + 3 + 3 (16 pieces), 6 + 4 + 2 + 2 (14), 4 + 4 + 2 + 2 (12: the 128 x 256 tile has 8 MFMAs per k-step to hide them behind)
-  static_assert(PA + PB == 16 || PA + PB == 14 || PA + PB == 12, "issue schedule");
-  constexpr int NP0 = PA + PB == 12 ? 4 : 6, NP1 = 4, NP2 = (PA + PB - NP0 - NP1) / 2, NP3 = NP2;
+  // 3 + 3 + 2 + 2 (10: the 192 x 128 tile has 6 MFMAs per k-step, a piece behind every other one at most)
+  static_assert(PA + PB == 16 || PA + PB == 14 || PA + PB == 12 || PA + PB == 10, "issue schedule");
+  constexpr int NP0 = PA + PB == 10 ? 3 : (PA + PB == 12 ? 4 : 6), NP1 = PA + PB == 10 ? 3 : 4, NP2 = (PA + PB - NP0 - NP1) / 2, NP3 = NP2;
   static_assert(NP0 + NP1 + NP2 + NP3 == PA + PB && PB >= NP0, "issue schedule");
   static_assert(!GEGLU || NT % 2 == 0, "GEGLU pairs 32-column sub-tiles (2q, 2q+1) of a wave");
   constexpr int ASZ = BM * ROWB, WSZ = BN * ROWB, WBASE = 3 * ASZ;        // ring: A slots 0..2, then W slots 0..1
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
       if (!(SP_ABL & 2)) {                                                                                  \
-        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? (MT * NT >= 12 ? 3 : 2) : ((NP) == 3 ? 4 : (MT * NT >= 12 ? 6 : 4))); \
+        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? (MT * NT >= 12 ? 3 : 2) : ((NP) == 3 ? (MT * NT >= 8 ? 4 : 2) : (MT * NT >= 12 ? 6 : (MT * NT >= 8 ? 4 : 3)))); \
         static_assert(STRIDE * ((NP) - 1) + 1 < MT * NT, "a DMA piece per MFMA gap at most");               \
         if (k % STRIDE == 1 && k / STRIDE < (NP)) {                                                         \
           issue_q((Q0) + k / STRIDE);                                                                       \
