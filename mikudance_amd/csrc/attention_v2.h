@@ -76,19 +76,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
   constexpr bool FOLD = (D % 16) == 8;         // softmax reference folded into the last k-step (see header)
 #endif
   constexpr int CONST_OFF = NST * STAGE;       // FOLD: two 16-B blocks {1,0,...,0}, 32 K rows apart (one per 32-key sub-tile)
-  // Head dims with D % 32 == 8 (40, 8) leave 9 useful rows (8 channels + the ones row) in the LAST 32-row tile of O^T: 23 of its 32
-  // MFMA rows multiply zeros (at d = 40: 4 of the 14 MFMAs of a key tile, 29 % of the matrix-pipe time).  Round 4: those rows run
-  // on v_mfma_f32_16x16x32_f16 instead (16 rows x 16 queries x 32 keys, half the cycles of a 32x32x16 each): per 32-key step the
-  // two P registers of a lane pair, X (keys 16c.. of its query) and Y (keys 16(c+1)..), become the two B operands (queries 0-15 /
-  // 16-31 in every 16-lane row) by ONE v_permlane16_swap per VGPR; the k-slot order that leaves (key octets 0, 2, 1, 3) is folded
-  // into the V^T fragment's LDS address.  448 -> 384 matrix-pipe cycles per 64-key tile for 8 swaps.  -DA2_NO_SMALLT: previous form.
-#ifdef A2_NO_SMALLT
-  constexpr bool SMALLT = false;
-#else
-  constexpr bool SMALLT = (D % 32) == 8;
-#endif
-  constexpr int DVB = SMALLT ? DVT - 1 : DVT;  // 32-row O^T tiles on the 32x32x16 MFMA
-  constexpr int DVA = DVB > 0 ? DVB : 1;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,18 +199,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
     }
   };
 
-  floatx16 o[QT][DVA];
-  floatx4 o1[QT][2];                                   // SMALLT: rows DVB*32 + 4 (lane / 16) + {0..3} of queries 16 nb + lane % 16
+  floatx16 o[QT][DVT];
   float m_run[QT], l_run[QT];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     m_run[u] = FOLD ? 0.f : NEG_BIG;
     l_run[u] = 0.f;
 #pragma unroll
-    for (int t = 0; t < DVB; ++t)
+    for (int t = 0; t < DVT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[u][t][r] = 0.f;
-    o1[u][0] = o1[u][1] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
   const int ntiles = (p.Lk + A2_KT - 1) / A2_KT;
 #pragma unroll
@@ -347,10 +332,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
           if (!first) {
             const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-            for (int t = 0; t < DVB; ++t)
+            for (int t = 0; t < DVT; ++t)
 #pragma unroll
               for (int r = 0; r < 16; ++r) o[u][t][r] *= alpha;
-            if (SMALLT) { o1[u][0] *= alpha; o1[u][1] *= alpha; }
           }
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub)
@@ -377,10 +361,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
           if (!first) {
             const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-            for (int t = 0; t < DVB; ++t)
+            for (int t = 0; t < DVT; ++t)
 #pragma unroll
               for (int r = 0; r < 16; ++r) o[u][t][r] *= alpha;
-            if (SMALLT) { o1[u][0] *= alpha; o1[u][1] *= alpha; }
           }
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub)
@@ -403,10 +386,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
         m_run[u] = m_new;
         l_run[u] *= alpha;
 #pragma unroll
-        for (int t = 0; t < DVB; ++t)
+        for (int t = 0; t < DVT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[u][t][r] *= alpha;
-        if (SMALLT) { o1[u][0] *= alpha; o1[u][1] *= alpha; }
       }
       float lsum = 0.f;
 #pragma unroll
@@ -423,7 +405,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
     }
     // ---- O^T += V^T P^T : one ds_read_b128 per V^T fragment, shared by the QT q-tiles
 #pragma unroll
-    for (int t = 0; t < DVB; ++t) {
+    for (int t = 0; t < DVT; ++t) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const half8_t vf = *reinterpret_cast<const half8_t*>(vs + (t * 32 + ql) * 128 + (((k * 2 + hi) ^ vsw) << 4));
@@ -437,68 +419,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
 #endif
       }
     }
-    if constexpr (SMALLT) {
-      // ---- last O^T tile (rows DVB*32 .. +15: 8 channels, the ones row, zeros) on 16x16x32: k-step ks covers keys 32 ks .. +31
-      const int m16 = lane & 15, g16 = lane >> 4;
-      const int oct = ((g16 & 1) << 1) | (g16 >> 1);                    // key octet of k-slots 8 g16 ..: (0, 2, 1, 3)[g16]
-      const int vsw16 = (m16 >> 1) & 7;                                 // slot swizzle of V^T row DVB*32 + m16
-      typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const half8_t vf = *reinterpret_cast<const half8_t*>(vs + (DVB * 32 + m16) * 128 + (((ks * 4 + oct) ^ vsw16) << 4));
-#pragma unroll
-        for (int u = 0; u < QT; ++u) {
-          uint4v x = __builtin_bit_cast(uint4v, pf[u][2 * ks]), y = __builtin_bit_cast(uint4v, pf[u][2 * ks + 1]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // x <- [x.row0, y.row0, x.row2, y.row2], y <- [x.row1, y.row1, x.row3, y.row3]  (rows of 16 lanes)
-            const auto sw = __builtin_amdgcn_permlane16_swap(x[e], y[e], false, false);
-            x[e] = sw[0];
-            y[e] = sw[1];
-          }
-          o1[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, __builtin_bit_cast(half8_t, x), o1[u][0], 0, 0, 0);
-          o1[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, __builtin_bit_cast(half8_t, y), o1[u][1], 0, 0, 0);
-        }
-      }
-    }
     if (++stage == NST) stage = 0;
   }
 
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
-    if constexpr (SMALLT) {
-      // sum_k P of query 16 nb + i sits in o1[nb][0] of lane 32 + i (row 8 = the ones row: lane / 16 == 2, register 0)
-      const int m16 = lane & 15, g16 = lane >> 4;
-      const float l0 = __shfl(o1[u][0][0], 32 + m16, 64), l1 = __shfl(o1[u][1][0], 32 + m16, 64);
-      {
-        const float inv = 1.0f / ((ql & 16) ? l1 : l0);                 // the 32x32 tiles: this lane's query is ql
-        const int qr = q0 + u * 32 + ql;
-        if (qr < p.Lq) {
-          half_t* Op = p.O + ((size_t)b * p.Lq + qr) * p.ldo + h * D;
-#pragma unroll
-          for (int t = 0; t < DVB; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int dv = t * 32 + 8 * g + 4 * hi;
-              half4_t ov = {(half_t)(o[u][t][4 * g] * inv), (half_t)(o[u][t][4 * g + 1] * inv), (half_t)(o[u][t][4 * g + 2] * inv),
-                            (half_t)(o[u][t][4 * g + 3] * inv)};
-              *reinterpret_cast<half4_t*>(Op + dv) = ov;
-            }
-        }
-      }
-      if (g16 < 2) {                                                    // the 16-row tile: channels DVB*32 + 4 g16 + {0..3}
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const float inv = 1.0f / (nb ? l1 : l0);
-          const int qr = q0 + u * 32 + nb * 16 + m16;
-          if (qr < p.Lq) {
-            half4_t ov = {(half_t)(o1[u][nb][0] * inv), (half_t)(o1[u][nb][1] * inv), (half_t)(o1[u][nb][2] * inv), (half_t)(o1[u][nb][3] * inv)};
-            *reinterpret_cast<half4_t*>(p.O + ((size_t)b * p.Lq + qr) * p.ldo + h * D + DVB * 32 + 4 * g16) = ov;
-          }
-        }
-      }
-      continue;
-    }
     float l_tot;
     if (ONES) {
       constexpr int rt = D % 32;                       // row of the ones inside the last tile; rt % 8 == 0 -> lane half 0

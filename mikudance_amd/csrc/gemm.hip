@@ -749,13 +749,26 @@ static int sp_row_blocks(const GemmParams& p, int* rows_per_block) {
   return cdiv(p.M, rows);
 }
 
+// Row blocks are only worth their extra launches when the blocks really run on the sp kernel: the first (full-size) block is
+// dispatched DRY first; anything but a 1xx plan (N not a multiple of 256 / 320 / 128, too few tiles) leaves the GEMM whole, on the
+// multi-workgroup kernel that addresses A with 64-bit pointers.
+template <bool GEGLU>
+static int sp_row_block_plan(const GemmParams& p, int sp, int force_nt, int ncu, int* rows) {
+  const int nb = sp > 0 ? sp_row_blocks(p, rows) : 1;
+  if (nb <= 1) return 1;
+  GemmParams c = p;
+  c.M = *rows;
+  const int plan = dispatch_any<false, GEGLU, true>(c, nullptr, sp, force_nt, ncu);
+  return plan / 100 == 1 ? nb : 1;
+}
+
 template <bool CONV, bool GEGLU>
 static void launch_any(GemmParams& p, hipStream_t stream) {
   static const int sp = env_int("MD_GEMM_SP", 2);
-  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 pin 192 x 320 / 192 x 256 / 128 x 256
+  static const int force_nt = env_int("MD_GEMM_SP_NT", 0);        // A/B runs only: 5 / 4 / 2 / 32 / 42 pin 192x320 / 192x256 / 128x256 / 192x128 / 256x128
   if constexpr (!CONV) {
     int rows;
-    const int nb = sp > 0 ? sp_row_blocks(p, &rows) : 1;
+    const int nb = sp_row_block_plan<GEGLU>(p, sp, force_nt, md_device_cus(), &rows);
     if (nb > 1) {
       for (int b = 0; b < nb; ++b) {
         GemmParams c = p;
@@ -877,9 +890,14 @@ extern "C" int md_gemm_plan(int M, int N, int K, int act, int transpose_out, int
   p.residual = (epi & 1) ? plan_ptr(3) : nullptr; p.rowadd = (epi & 2) ? plan_ptr(4) : nullptr; p.bias = (epi & 4) ? plan_ptr(5) : nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = transpose_out ? M : (act == ACT_GEGLU ? N / 2 : N); p.ldr = N; p.ldra = N;
   p.rows_per_group = M; p.act = act; p.transpose_out = transpose_out;
+  // a token matrix beyond 2^31 bytes runs in row blocks when they take the sp kernel: the plan returned is that of the FIRST (full-size)
+  // block; the shorter last block is dispatched on its own (same rule, possibly a smaller tile) -- query it with its own M
   int rows;
-  if (sp_row_blocks(p, &rows) > 1) p.M = rows;                   // a token matrix beyond 2^31 bytes runs in row blocks: plan of a block
-  if (act == ACT_GEGLU) return dispatch_any<false, true, true>(p, nullptr, 2, 0, ncu);
+  if (act == ACT_GEGLU) {
+    if (sp_row_block_plan<true>(p, 2, 0, ncu, &rows) > 1) p.M = rows;
+    return dispatch_any<false, true, true>(p, nullptr, 2, 0, ncu);
+  }
+  if (sp_row_block_plan<false>(p, 2, 0, ncu, &rows) > 1) p.M = rows;
   return dispatch_any<false, false, true>(p, nullptr, 2, 0, ncu);
 }
 

@@ -47,6 +47,21 @@ def test_gelu_fast_matches_erf_gelu():
     assert gelu_fast(torch.tensor([65504.0]))[0].item() == 65504.0
 
 
+def test_gelu_fast_non_finite_inputs_behave_like_aten():
+    """+inf: p^16 = inf, r = 0, |x| r = inf * 0 = NaN.  A non-finite pre-activation needs a non-finite INPUT of the GEMM (fp16 operands,
+    K <= 5120 terms and an fp16 bias bound the fp32 accumulator by 2.2e13), and ATen's own erf GELU (x * 0.5 * (1 + erf(x / sqrt 2)),
+    what diffusers GEGLU calls) answers NaN to -inf and NaN as well; for +inf this formula says NaN where ATen's vectorised CPU kernel
+    says NaN and its scalar tail inf -- both mean "the activations overflowed upstream".  A select on r == 0 would make +inf map to
+    +inf at the price of 2-3 more issue slots per output pair in a VALU-bound epilogue (11 today): not spent."""
+    x = torch.tensor([float("inf"), float("-inf"), float("nan")])
+    got = gelu_fast(x)
+    assert torch.isnan(got).all()
+    ref = torch.nn.functional.gelu(x.repeat_interleave(16))       # 16 copies: the vectorised path of the CPU kernel
+    assert torch.isnan(ref[16:]).all()                            # -inf, NaN: ATen says NaN too
+    big = torch.tensor([1e30, -1e30, 3e38, -3e38])                # finite, far beyond fp16: exact
+    assert torch.equal(gelu_fast(big), big.clamp_min(0.0))
+
+
 def test_quick_gelu_is_the_clip_activation():
     # CLIP's quick_gelu (transformers activations.QuickGELUActivation): x * sigmoid(1.702 x), the ACT_QUICKGELU epilogue
     x = torch.linspace(-10, 10, 2001)

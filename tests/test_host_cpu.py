@@ -167,7 +167,7 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
     """The automatic kernel choice for every MFMA-bound launch shape of configs[1] (768 x 768, 16 frames, CFG: 32-frame batches), as
     measured best on MI355X in same-box A/B runs (profiles/r03_ab_gemm_sp_tiles.log, r03_ab_gemm_sp_tile_128x256.log,
     r03_ab_transposed_sp.log).  md_gemm_plan / md_conv3x3_plan run the launcher's own decision code without
-    touching a device: 135 / 134 / 124 = gemm_sp_kernel 192x320 / 192x256 / 128x256, 144 = its 256x256 GEGLU flavour, +1000 on
+    touching a device: 135 / 134 / 124 / 132 / 142 = gemm_sp_kernel 192x320 / 192x256 / 128x256 / 192x128 / 256x128, 144 = its 256x256 GEGLU flavour, +1000 on
     swapped operands (transposed output), 210 / 220 / 230 = W-stationary streaming kernel, 301 / 303 = multi-workgroup kernel."""
     from mikudance_amd import _lib, ops
     lib = _lib.load()
@@ -180,8 +180,10 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
         # level 2 (24 x 24): N = 1280 takes the 192 x 256 tile (480 tiles = 1.9 rounds instead of 384 = 1.5)
         (18432, 1280, 1280, 0, 0, 5): 134, (18432, 10240, 1280, G, 0, 4): 144, (18432, 1280, 5120, 0, 0, 5): 134, (18432, 3840, 1280, 0, 0, 0): 135,
         (18432, 2560, 1280, 0, 0, 0): 135,
-        # level 3 (12 x 12): 128 x 256 tiles fill more CUs
-        (4608, 1280, 1280, 0, 0, 5): 124, (4608, 10240, 1280, G, 0, 4): 144, (4608, 1280, 5120, 0, 0, 5): 124, (4608, 2560, 1280, 0, 0, 0): 134,
+        # level 3 (12 x 12): N = 1280 on 192 x 128 tiles (24 x 10 = 240 of them fill 256 CUs; 128 x 256 gives 180): +14..16 % same-box
+        # (profiles/r04_ab_tile_192x128.log); the wider N keep the 192 x 256 tile
+        (4608, 1280, 1280, 0, 0, 5): 132, (4608, 10240, 1280, G, 0, 4): 144, (4608, 1280, 5120, 0, 0, 5): 132, (4608, 2560, 1280, 0, 0, 0): 134,
+        (4608, 3840, 1280, 0, 0, 0): 134,
         # V^T projections (transposed output): swapped operands
         (294912, 320, 320, 0, 1, 0): 1134, (73728, 640, 640, 0, 1, 0): 1124, (18432, 1280, 1280, 0, 1, 0): 1134, (4608, 1280, 1280, 0, 1, 0): 1124,
         # not sp: ragged / tiny N, few tiles
@@ -191,10 +193,12 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
         assert lib.md_gemm_plan(*args, ncu) == want, (args, lib.md_gemm_plan(*args, ncu), want)
     conv = {  # (B, H = W, Cin, Cout, stride, upsample)
         (32, 96, 320, 320, 1, 0): 135, (32, 96, 640, 320, 1, 0): 135, (32, 96, 960, 320, 1, 0): 135, (32, 48, 640, 640, 1, 0): 135,
-        (32, 48, 1920, 640, 1, 0): 135, (32, 24, 1280, 1280, 1, 0): 134, (32, 24, 2560, 1280, 1, 0): 134, (32, 12, 1280, 1280, 1, 0): 124,
-        (32, 12, 2560, 1280, 1, 0): 124, (32, 48, 640, 640, 1, 1): 135, (32, 24, 1280, 1280, 1, 1): 135, (32, 12, 1280, 1280, 1, 1): 134,
-        (32, 96, 320, 320, 2, 0): 135, (32, 48, 640, 640, 2, 0): 135, (32, 24, 1280, 1280, 2, 0): 124, (32, 96, 320, 4, 1, 0): 301,
+        (32, 48, 1920, 640, 1, 0): 135, (32, 24, 1280, 1280, 1, 0): 134, (32, 24, 2560, 1280, 1, 0): 134, (32, 12, 1280, 1280, 1, 0): 132,
+        (32, 12, 2560, 1280, 1, 0): 132, (32, 48, 640, 640, 1, 1): 135, (32, 24, 1280, 1280, 1, 1): 135, (32, 12, 1280, 1280, 1, 1): 134,
+        (32, 96, 320, 320, 2, 0): 135, (32, 48, 640, 640, 2, 0): 135, (32, 24, 1280, 1280, 2, 0): 132, (32, 96, 320, 4, 1, 0): 301,
         (2, 8, 64, 320, 1, 0): 303,
+        # AutoencoderKL at 768 x 768, 8 images per call: the 128-channel layers (N % 128 only) on the 256 x 128 tile, 256 channels on 192 x 256
+        (8, 768, 64, 128, 1, 0): 142, (8, 768, 128, 128, 1, 0): 142, (8, 384, 128, 256, 1, 0): 134, (8, 384, 256, 256, 1, 0): 134,
     }
     for (B, H, cin, cout, st, up), want in conv.items():
         got = lib.md_conv3x3_plan(B, H, H, cin, cout, st, up, 4, ncu)
