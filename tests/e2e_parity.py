@@ -96,9 +96,15 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--latent", type=int, default=96)
     ap.add_argument("--no-fp16-oracle", action="store_true")
+    ap.add_argument("--config4", action="store_true", help="BASELINE configs[4] geometry: 128 x 128 latents, 48 frames in 3 wrapping windows of 30 "
+                    "(context 30 / overlap 8), --steps DDIM steps of the 30 (default 2: the restatement runs ~1.5 PFLOP per step in fp32)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    r = run(a.frames, a.steps, a.latent, with_fp16_oracle=not a.no_fp16_oracle, log=lambda *m: print(*m, flush=True))
+    if a.config4:
+        a.frames, a.latent = 48, 128
+        a.steps = a.steps if a.steps != 20 else 2
+    r = run(a.frames, a.steps, a.latent, with_fp16_oracle=not a.no_fp16_oracle, log=lambda *m: print(*m, flush=True),
+            window=dict(context_frames=30, context_stride=1, context_overlap=8) if a.config4 else None)
     r["device"] = torch.cuda.get_device_name(0)
     print(json.dumps(r))
     if a.out:
