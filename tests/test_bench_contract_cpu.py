@@ -54,6 +54,30 @@ def test_roofline_and_cpu_baseline_objects():
     assert 0.0 < d["mfma_frac_whole_loop"] < 1.0
 
 
+def test_round4_line_measures_its_own_traffic_and_quotes_the_best_cpu_thread_count():
+    d = _record("r04_bench.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "768" in base["metric"] and "768x768" in d["metric"] and "configs[1]" in d["config"]["workload"]
+    assert d["n_gpus"] == d["n_ranks_seen"] == 1 and d["config"]["input_staging"].startswith("rank-local")
+    frames = int(re.search(r"(\d+)f,", d["metric"]).group(1))
+    assert math.isclose(d["value"], frames / (d["ms_per_step"] * 1e-3), rel_tol=1e-6)
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-9) and 0.25 < r["frac"] < 1.0
+    # achieved = algorithmic FLOPs of the launch / its HIP-event average
+    B, H, D, Lq, Lk = map(int, re.match(r"attention B=(\d+) H=(\d+) D=(\d+) Lq=(\d+) Lk=(\d+)", r["kernel"]).groups())
+    assert math.isclose(r["achieved"], 4.0 * B * H * Lq * Lk * D / (r["avg_ms"] * 1e-3) / 1e12, rel_tol=1e-6)
+    src = r["traffic_source"]
+    assert "measured" in src and "separate passes" in src["measured"]                     # this run's own PMC passes, not a file
+    assert math.isclose(r["traffic"], (2.0 * src["FETCH_SIZE_KiB"] + src["WRITE_SIZE_KiB"]) * 1024.0, rel_tol=1e-9)
+    assert r["traffic"] >= r["algorithmic_bytes"] == 2.0 * B * H * D * (2 * Lq + 2 * Lk)
+    c = d["cpu_baseline"]
+    sweep = {int(k): v for k, v in c["thread_sweep_s_per_step_at_size"].items()}
+    assert c["cores"] == min(sweep, key=sweep.get) and len(sweep) >= 3 and c["kind"] == "port"
+    assert math.isclose(c["value"], 1.0 / (sweep[c["cores"]] * 20), rel_tol=2e-2) and c["value"] < d["value"]
+    assert "extrapolated" in c["sample"]
+    assert 0.0 < d["mfma_frac_whole_loop"] < 1.0 and d["e2e_frames_per_s"] < d["value"]
+
+
 def test_other_records_are_labelled_with_their_config():
     assert "configs[2]" in _record("r02_bench_cfg2.json")["config"]["workload"]
     c4 = _record("r02_bench_cfg4.json")
