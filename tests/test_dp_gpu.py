@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
         sys.path.insert(0, ROOT)
         os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           MD_DIST_BACKEND="gloo")
-        torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+        # the oracle's small operators run ~7x slower on 64 threads than on 16 (tests/conftest.py); two ranks share the host
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 2) // world)))
         import torch.distributed as dist
         from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline, dp
         from mikudance_amd.selftest import SCHED_KWARGS, build_models, cosine, rel_l2
