@@ -131,6 +131,103 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ GroupNorm, small images: ONE sweep
+// The 24 x 24 and 12 x 12 levels (HW = 576 / 144, C = 1280 ... 2560) are 12-47 MB per launch: the two-kernel form above spends them on
+// launch latency and on a re-read (1.4 TB/s at HW = 144, 3.3 at HW = 576 against 4.4-4.7 on the large levels).  Here ONE 256-thread
+// workgroup owns a whole (image, group): HW x cpg values (<= 46 080) sit in its REGISTERS as 8-byte pieces, so the tensor is read once,
+// the statistics are the exact two-pass ones (mean, then sum of (x - mean)^2: no pilot needed, nothing to cancel), and the normalised
+// values are written from the registers: 4 bytes per element instead of 6, one launch instead of two, no workspace.  Thread (tc, tp):
+// piece tc of the group's cpg / 4 pieces of a pixel, pixel lane tp; it visits pixels tp, tp + R, ...  (at most NIT of them).  The 80-byte
+// (cpg = 40) slices of a 2560-byte pixel row share cache lines with the neighbouring groups' workgroups: at these sizes the tensor
+// lives in L2 / the memory-side cache, so that costs requests, not HBM bytes; the large levels stay on the two-kernel form.
+template <int NIT, int NT>
+__global__ __launch_bounds__(NT) void gn_small_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const half_t* __restrict__ gamma,
+                                                       const half_t* __restrict__ beta, int HW, int C, int ldx, int cpg, int R, float eps, int silu, int B) {
+  constexpr int NWV = NT / 64;
+  __shared__ float red[2][NWV];
+  const int cpr = cpg >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tc = tid % cpr, tp = tid / cpr;
+  // workgroup L runs on XCD L % 8 (observed dispatch order, speed only): give each XCD G / 8 CONSECUTIVE groups of every image, so that
+  // the cache lines two neighbouring groups share (a group's slice of a pixel row is 40-160 bytes) are fetched into ONE L2
+  const int G = gridDim.x / B, L = blockIdx.x;                  // 1-D grid of B * G workgroups
+  const int b = L / G, l = L - b * G;
+  const int g = (G & 7) ? l : (l & 7) * (G >> 3) + (l >> 3);
+  const bool live = tp < R;
+  const half_t* xb = x + (size_t)b * HW * ldx + g * cpg + tc * 4;
+  half4_t v[NIT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int p = tp + i * R;
+    v[i] = half4_t{0, 0, 0, 0};
+    if (live && p < HW) v[i] = *reinterpret_cast<const half4_t*>(xb + (size_t)p * ldx);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) s += ((float)v[i][0] + (float)v[i][1]) + ((float)v[i][2] + (float)v[i][3]);
+  s = wave_sum(s);
+  if (lane == 0) red[0][wave] = s;
+  __syncthreads();
+  const float n = (float)HW * (float)cpg;
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) tot += red[0][w];
+  const float mean = tot / n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int p = tp + i * R;
+    if (live && p < HW) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = (float)v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[1][wave] = q;
+  __syncthreads();
+  float qt = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) qt += red[1][w];
+  const float rstd = rsqrtf(qt / n + eps);
+  if (!live) return;
+  const half4_t gm = *reinterpret_cast<const half4_t*>(gamma + g * cpg + tc * 4), bt = *reinterpret_cast<const half4_t*>(beta + g * cpg + tc * 4);
+  float sc[4], sf[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = rstd * (float)gm[e];
+    sf[e] = (float)bt[e] - mean * sc[e];
+  }
+  half_t* yb = y + (size_t)b * HW * C + g * cpg + tc * 4;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int p = tp + i * R;
+    if (p < HW) {
+      half4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float f = (float)v[i][e] * sc[e] + sf[e];
+        if (silu) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      *reinterpret_cast<half4_t*>(yb + (size_t)p * C) = o;
+    }
+  }
+}
+
+// the one-sweep form applies when a group's channels are whole 8-byte pieces, an (image, group) fits the registers of 256 threads and
+// the grid fills the chip; returns the sweeps per thread (0: use the two-kernel form)
+static int gn_small_iters(int B, int HW, int C, int G, int* R, int* NT) {
+  const int cpg = C / G;
+  if (cpg % 4 || cpg / 4 > 64 || (long)B * G < 256 || HW > 1024) return 0;      // HW = 2304, C = 640 (94 MB: HBM-bound) measured 10 % SLOWER: 40-byte slices
+  *NT = cdiv(HW, 256 / (cpg / 4)) > 24 ? 512 : 256;            // <= 24 sweeps per thread (139 registers: 3 waves per SIMD)
+  *R = *NT / (cpg / 4);
+  const int it = cdiv(HW, *R);
+  return it <= 24 ? it : 0;
+}
+
 // Launch geometry: R row lanes per 8-channel chunk (~512 threads), slabs of GN_SLAB rows per lane -- halved while the grid would
 // not give every CU two workgroups (small images).
 static void gn_geometry(int B, int HW, int C, int& R, int& slab, int& nslab) {
@@ -156,6 +253,24 @@ extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const v
                "md_groupnorm: ldx=%d must be a multiple of 8 and >= C=%d, x 16-byte aligned; in place only with ldx == C", ldx, C);
   MD_CHECK_ARG(C / 8 <= 1024, "md_groupnorm: C=%d too large", C);
   MD_CHECK_ARG(ws_bytes >= md_groupnorm_workspace_bytes(B, HW, C, G), "md_groupnorm: workspace too small");
+  {
+    int Rs, NTs;
+    const int it = (ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0) ? gn_small_iters(B, HW, C, G, &Rs, &NTs) : 0;
+    if (it) {
+#define GN_SMALL(N, T)                                                                                                                       \
+  hipLaunchKernelGGL((gn_small_kernel<N, T>), dim3(B * G), dim3(T), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const half_t*)gamma, \
+                     (const half_t*)beta, HW, C, ldx, C / G, Rs, eps, silu, B)
+      if (NTs == 512) {
+        if (it <= 12) GN_SMALL(12, 512);
+        else GN_SMALL(24, 512);
+      } else if (it <= 6) GN_SMALL(6, 256);
+      else if (it <= 12) GN_SMALL(12, 256);
+      else GN_SMALL(24, 256);
+#undef GN_SMALL
+      MD_CHECK_LAUNCH("md_groupnorm");
+      return MD_OK;
+    }
+  }
   const int cch = C / 8;
   int R, slab, nslab;
   gn_geometry(B, HW, C, R, slab, nslab);

@@ -547,6 +547,33 @@ def test_groupnorm_on_a_channel_slice(dev, B, H, W, C, lead, tail, silu):
         ops.groupnorm(wide[..., 4:4 + C] if lead + tail >= 4 else x[:, :, ::2], g, b, 32, 1e-5)   # unaligned slice / non-uniform pitch
 
 
+@pytest.mark.parametrize("B,HW,C,silu,lead", [(32, 144, 1280, True, 0), (32, 576, 1280, False, 0), (8, 576, 2560, True, 0), (9, 575, 1920, True, 0),
+                                              (16, 144, 1280, True, 1280), (32, 576, 640, False, 64), (8, 1000, 1280, True, 0), (8, 144, 128, True, 0)])
+def test_groupnorm_one_sweep_small_images(dev, B, HW, C, silu, lead):
+    """gn_small_kernel: one workgroup per (image, group) holds its HW x C/32 values in registers (the 24 x 24 / 12 x 12 levels; chosen when
+    C / 32 is a multiple of 4, B * 32 >= 256 and HW <= 1024 fits 24 sweeps): contiguous and channel-slice inputs, ragged HW, in place,
+    exact two-pass statistics (|mean| = 800 sigma), bitwise run-to-run identical."""
+    wide = rnd(B, HW, lead + C, seed=90).to(dev)
+    wide = wide + 3.0 * torch.arange(lead + C, device=dev).remainder(5).half()
+    x = wide[..., lead:]
+    g, b = (1 + 0.1 * rnd(C, seed=91)).to(dev), rnd(C, seed=92).to(dev)
+    ref = F.group_norm(x.float().cpu().permute(0, 2, 1), 32, g.float().cpu(), b.float().cpu(), 1e-5).permute(0, 2, 1)
+    ref = F.silu(ref) if silu else ref
+    got = ops.groupnorm(x, g, b, 32, 1e-5, silu=silu)
+    close(got, ref, what="groupnorm one sweep")
+    assert torch.equal(got, ops.groupnorm(x, g, b, 32, 1e-5, silu=silu))
+    if lead == 0:
+        xc = x.clone()
+        ops.groupnorm(xc, g, b, 32, 1e-5, silu=silu, out=xc)                       # in place
+        assert torch.equal(xc, got)
+    # a group whose mean dwarfs its spread: statistics must not cancel
+    big = (800.0 + 1.0 * torch.randn(B, HW, C, generator=torch.Generator().manual_seed(93))).half().to(dev)
+    refb = F.group_norm(big.float().cpu().permute(0, 2, 1), 32, None, None, 1e-5).permute(0, 2, 1)
+    one, zero = torch.ones(C, device=dev, dtype=torch.float16), torch.zeros(C, device=dev, dtype=torch.float16)
+    gotb = ops.groupnorm(big, one, zero, 32, 1e-5).float().cpu()
+    assert (gotb - refb).abs().max() <= 2e-2 * refb.abs().max() + 2e-3
+
+
 def test_instnorm_spade_on_a_channel_slice(dev):
     B, HW, C = 3, 150, 128
     wide = rnd(B, HW, C + 192, seed=63).to(dev)
