@@ -18,6 +18,7 @@ has (no omegaconf / diffusers / PyAV / cv2 / torchvision / scikit-image): see mi
 `--video_decoder` selects mikudance_amd.AutoencoderKLTemporalDecoder (config.pretrained_temporal_vae_path), like the reference (:72-75)."""
 import argparse
 import os
+import warnings
 from datetime import datetime
 from pathlib import Path
 
@@ -78,7 +79,11 @@ def main(argv=None):
     config = load_config(args.config)
     weight_dtype = torch.float16 if config.weight_dtype == "fp16" else torch.float32
     if weight_dtype != torch.float16:
-        raise NotImplementedError("the MI355X kernels compute in fp16 (weight_dtype: 'fp16', the reference's shipped setting)")
+        # reference scripts/inference_video.py:66-69 runs the whole model in fp32 then.  Here parameters, latents and images keep
+        # the requested dtype at every module boundary, and the kernels underneath still round operands to fp16 and accumulate in
+        # fp32: over the 20-step loop that is 2.4e-3 relative L2 from the fp32 restatement (profiles/r04_e2e_parity.json)
+        warnings.warn("weight_dtype: fp32 -- tensors are kept in fp32 at the module boundaries; the MI355X kernels compute with fp16 "
+                      "operands and fp32 accumulation")
     infer_config = load_config(config.inference_config)
     generator = torch.manual_seed(args.seed)
     width, height = args.W, args.H

@@ -26,6 +26,12 @@ def _chk(t, name, dtype=F16):
         raise _lib.MdanceHipError(f"{name} must be {dtype}, got {t.dtype}")
 
 
+def require_gpu(t, who):
+    """Entry check of the host-side loops: there is no CPU path behind them (the operators below check again, per tensor)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: tensors must live on the MI355X; there is no CPU path")
+
+
 def _rowmajor(t, name):
     _chk(t, name)
     if t.dim() != 2 or t.stride(1) != 1:

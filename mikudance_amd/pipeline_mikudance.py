@@ -131,8 +131,7 @@ class MikuDanceVideoPipeline:
         returns latents (1, 4, F, h, w) in the input dtype.
         """
         dev = latents.device
-        if dev.type != "cuda":
-            raise RuntimeError("MikuDanceVideoPipeline.denoise: tensors must live on the MI355X; there is no CPU path")
+        ops.require_gpu(latents, "MikuDanceVideoPipeline.denoise")
         context_frames = context_frames or self.default_context_frames
         do_cfg = guidance_scale > 1.0
         nb = 2 if do_cfg else 1

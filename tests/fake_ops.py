@@ -226,10 +226,51 @@ def cfg_ddim_step(latents, noise_sum, counter, ftot, hw, guidance, alpha_t, alph
     latents.copy_(out.view(latents.shape).to(F16))
 
 
+# ------------------------------------------------------------------ duck-typed modules either side of the loop
+class FakeVAE(torch.nn.Module):
+    """Duck-typed stand-in for diffusers AutoencoderKL (the pipeline only touches encode().latent_dist.mean, decode().sample,
+    .dtype, .device): 8x average pooling to 4 channels and nearest upsampling back."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    dtype = property(lambda self: self.p.dtype)
+    device = property(lambda self: self.p.device)
+
+    def encode(self, x):
+        z = torch.nn.functional.avg_pool2d(x, 8)
+        z = torch.cat([z, z.mean(1, keepdim=True)], 1)
+        return type("E", (), {"latent_dist": type("D", (), {"mean": z})})
+
+    def decode(self, z, **kw):
+        return type("S", (), {"sample": torch.nn.functional.interpolate(z[:, :3], scale_factor=8.0, mode="nearest")})
+
+
+class FakeCLIP(torch.nn.Module):
+    def __init__(self, tokens=5, dim=64):
+        super().__init__()
+        self.tokens, self.dim = tokens, dim
+        self.vision_model = type("V", (), {"post_layernorm": torch.nn.Identity()})()
+        self.visual_projection = torch.nn.Identity()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    dtype = property(lambda self: self.p.dtype)
+
+    def forward(self, pixel_values):
+        g = torch.Generator().manual_seed(3)
+        h = torch.randn(1, self.tokens, self.dim, generator=g).to(pixel_values.device, pixel_values.dtype)
+        return type("O", (), {"last_hidden_state": h + pixel_values.mean() * 0})
+
+
+def require_gpu(t, who):
+    pass
+
+
 def install(monkeypatch):
     """Replace the functions of mikudance_amd.ops by the emulations above for the duration of a test."""
     from mikudance_amd import ops
     for name in ("gemm", "conv3x3", "groupnorm", "layernorm", "instnorm_spade", "attention", "softmax_rows_", "temporal_attention", "pack_nhwc",
-                 "unpack_nhwc", "concat_channels", "window_accumulate", "cfg_ddim_step"):
+                 "unpack_nhwc", "concat_channels", "window_accumulate", "cfg_ddim_step", "require_gpu"):
         monkeypatch.setattr(ops, name, globals()[name])
     del CALLS[:]

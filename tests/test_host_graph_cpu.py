@@ -103,3 +103,97 @@ def test_autoencoder_kl_graph_on_emulated_operators(monkeypatch):
         want_m, want_x = O.vae_encode_moments(sd, img), O.vae_decode(sd, z)
     assert rel_l2(vae.encode(img.half()).latent_dist.mean.float(), want_m[:, :4]) < 2e-2
     assert rel_l2(vae.decode(z.half()).sample.float(), want_x) < 2e-2
+
+
+@pytest.mark.parametrize("case", ["single_window", "wrapping_windows", "no_cfg", "eta", "literal_reference_pass"])
+def test_denoise_loop_on_emulated_operators_matches_the_oracle(small, monkeypatch, case):
+    """MikuDanceVideoPipeline.denoise -- the loop of reference src/pipelines/pipeline_mikudance.py:573-686 -- on the emulated
+    operator layer: window lists and their duplicate-frame slots, the bank cache across steps (reference UNet once per window), the
+    [u,c,u,c] context quirk, fp32 window accumulation, CFG, the DDIM step (eta = 0 and eta > 0 with the generator's draws), the
+    NCFHW <-> NHWC packing at both ends.  Against oracle/cpu_ref.denoise_loop on the same fp16-representable inputs."""
+    from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline
+    from mikudance_amd.selftest import SCHED_KWARGS
+    ref, den, ref_sd, den_sd = small
+    fake_ops.install(monkeypatch)
+    F_, steps, guidance, kw, okw = 3, 2, 3.5, {}, {}
+    if case == "wrapping_windows":
+        F_, win = 6, dict(context_frames=4, context_stride=1, context_overlap=2)
+        kw, okw = dict(win), dict(win)
+    elif case == "no_cfg":
+        guidance = 1.0
+    elif case == "eta":
+        kw = dict(eta=0.5, generator=torch.Generator().manual_seed(11))
+        okw = dict(eta=0.5, generator=torch.Generator().manual_seed(11), noise_dtype=torch.float16)
+    lat, rl, emb = (t.half() for t in synth_inputs(F_, 16, 16, ctx_len=5, ctx_dim=64, seed=9))
+    if guidance <= 1.0:
+        emb = emb[1:]
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    pipe.reference_reuse = case != "literal_reference_pass"
+    seen = []
+    before = (lat.clone(), rl.clone(), emb.clone())
+    got = pipe.denoise(lat, rl, emb, steps, guidance, callback=lambda i, t, x: seen.append((i, t, x.float())), **kw)
+    assert got.dtype == torch.float16 and got.shape == lat.shape
+    assert all(torch.equal(a, b) for a, b in zip(before, (lat, rl, emb)))               # the pipeline never mutates its inputs
+    curve = []
+    with torch.no_grad():
+        want = O.denoise_loop(ref_sd, den_sd, lat.float(), rl.float(), emb.float(), steps, guidance_scale=guidance,
+                              reduced=case != "literal_reference_pass", on_step=lambda t, x: curve.append((t, x.float())), **okw)
+    r, c = rel_l2(got.float(), want), cosine(got.float(), want)
+    assert r < 2e-2 and c > 0.999, (case, r, c)
+    assert [s[1] for s in seen] == [int(t) for t, _ in curve] and len(seen) == steps
+    for (_, _, a), (_, b) in zip(seen, curve):
+        assert rel_l2(a, b) < 2e-2
+    # nothing outlives the clip: banks dropped, context caches empty
+    from mikudance_amd import ReferenceAttentionControl as RAC
+    assert all(not blk.bank for blk in RAC(den, mode="read", fusion_blocks="full")._blocks(den))
+    assert not den._cross_cache and not ref._cross_cache
+
+
+def test_fp32_typed_boundary_is_the_fp16_run(small, monkeypatch):
+    """`weight_dtype: fp32` (reference scripts/inference_video.py:66-69): .float() models re-pack their kernel-layout weights, fp32
+    latents / context are converted at the edge, results come back in fp32 -- and equal the fp16 run on fp16-representable values."""
+    from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline
+    from mikudance_amd.selftest import SCHED_KWARGS
+    ref, den, _, _ = small
+    fake_ops.install(monkeypatch)
+    lat, rl, emb = (t.half() for t in synth_inputs(2, 16, 16, ctx_len=5, ctx_dim=64, seed=3))
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    out16 = pipe.denoise(lat, rl, emb, 2, 3.5)
+    try:
+        ref.float(); den.float()
+        assert den.dtype == ref.dtype == torch.float32
+        out32 = pipe.denoise(lat.float(), rl.float(), emb.float(), 2, 3.5)
+    finally:
+        ref.half(); den.half()
+    assert out32.dtype == torch.float32 and torch.equal(out32.half(), out16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_pipeline_call_on_emulated_operators(small, monkeypatch, dtype):
+    """MikuDanceVideoPipeline.__call__ (reference src/pipelines/pipeline_mikudance.py:363-704) with the reference script's positional
+    order, PIL inputs and a CPU generator, duck-typed VAE / CLIP, in both weight dtypes: guidance assembly (22 channels), latent
+    preparation, the loop, decode, the (1, 3, F, H, W) float32 CPU video in [0, 1]."""
+    import numpy as np
+    from PIL import Image
+    from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline
+    from mikudance_amd.selftest import SCHED_KWARGS
+    ref, den, _, _ = small
+    fake_ops.install(monkeypatch)
+    H = W = 128
+    F_ = 2
+    rng = np.random.default_rng(0)
+    img = lambda: Image.fromarray(rng.integers(0, 255, (160, 144, 3), dtype=np.uint8))
+    flow = rng.uniform(-0.03, 0.03, (F_, 2, H // 8, W // 8))
+    pipe = MikuDanceVideoPipeline(vae=fake_ops.FakeVAE(), image_encoder=fake_ops.FakeCLIP(), reference_unet=ref, denoising_unet=den,
+                                  scheduler=DDIMScheduler(**SCHED_KWARGS))
+    try:
+        pipe = pipe.to("cpu", dtype=dtype)
+        assert den.dtype == dtype
+        seen = []
+        v = pipe(img(), img(), [img() for _ in range(F_)], [img() for _ in range(F_)], [img() for _ in range(F_)], flow, W, H, F_, 2, 3.5,
+                 generator=torch.manual_seed(42), callback=lambda i, t, x: seen.append(x.dtype)).videos
+    finally:
+        ref.half(); den.half()
+    assert tuple(v.shape) == (1, 3, F_, H, W) and v.dtype == torch.float32 and torch.isfinite(v).all()
+    assert float(v.min()) >= 0.0 and float(v.max()) <= 1.0 and float(v.std()) > 0
+    assert seen == [dtype, dtype]                                    # latents keep the requested dtype at the boundary

@@ -112,3 +112,14 @@ def test_inference_video_script_end_to_end(tmp_path, golden_dir):
                                  "--seed", "7", "--video_decoder", "--output_dir", str(tmp_path / "output_t")])
     f2 = U.read_frames(out2)
     assert len(f2) == F_ and f2[0].size == frames[0].size and np.isfinite(np.asarray(f2[0], dtype=np.float32)).all()
+    # weight_dtype: fp32 (reference scripts/inference_video.py:66-69): accepted with a warning, fp32 at the module boundaries
+    # (bit-identity with the fp16 run on equal inputs: tests/test_unets_gpu.py::test_fp32_typed_models_and_latents_match_fp16_run)
+    cfg = yaml.safe_load(open(tmp_path / "configs" / "inference_video.yaml"))
+    cfg["weight_dtype"] = "fp32"
+    yaml.safe_dump(cfg, open(tmp_path / "configs" / "inference_video_fp32.yaml", "w"))
+    with pytest.warns(UserWarning, match="fp32"):
+        out3 = inference_video.main(["--config", str(tmp_path / "configs" / "inference_video_fp32.yaml"), "-W", str(W), "-H", str(H), "--steps", "2",
+                                     "--seed", "7", "--output_dir", str(tmp_path / "output_fp32")])
+    f3 = U.read_frames(out3)
+    a3 = np.asarray(f3[0], dtype=np.float32)
+    assert len(f3) == F_ and f3[0].size == frames[0].size and np.isfinite(a3).all() and a3[:, 2 * (W + 2):].std() > 0

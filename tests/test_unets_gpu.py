@@ -352,40 +352,7 @@ def test_g10_plain_groupnorm_vs_reference_golden(small, golden_dir):
     assert rel_l2(pred_inflated.float(), gold) > 2 * r
 
 
-class _FakeVAE(torch.nn.Module):
-    """Duck-typed stand-in for diffusers AutoencoderKL (the pipeline only touches encode().latent_dist.mean, decode().sample,
-    .dtype, .device): 8x average pooling to 4 channels and nearest upsampling back."""
-
-    def __init__(self):
-        super().__init__()
-        self.p = torch.nn.Parameter(torch.zeros(1))
-
-    dtype = property(lambda self: self.p.dtype)
-    device = property(lambda self: self.p.device)
-
-    def encode(self, x):
-        z = torch.nn.functional.avg_pool2d(x, 8)
-        z = torch.cat([z, z.mean(1, keepdim=True)], 1)
-        return type("E", (), {"latent_dist": type("D", (), {"mean": z})})
-
-    def decode(self, z, **kw):
-        return type("S", (), {"sample": torch.nn.functional.interpolate(z[:, :3], scale_factor=8.0, mode="nearest")})
-
-
-class _FakeCLIP(torch.nn.Module):
-    def __init__(self, tokens=5, dim=64):
-        super().__init__()
-        self.tokens, self.dim = tokens, dim
-        self.vision_model = type("V", (), {"post_layernorm": torch.nn.Identity()})()
-        self.visual_projection = torch.nn.Identity()
-        self.p = torch.nn.Parameter(torch.zeros(1))
-
-    dtype = property(lambda self: self.p.dtype)
-
-    def forward(self, pixel_values):
-        g = torch.Generator().manual_seed(3)
-        h = torch.randn(1, self.tokens, self.dim, generator=g).to(pixel_values.device, pixel_values.dtype)
-        return type("O", (), {"last_hidden_state": h + pixel_values.mean() * 0})
+from fake_ops import FakeCLIP as _FakeCLIP, FakeVAE as _FakeVAE  # noqa: E402  (duck-typed VAE / CLIP stand-ins)
 
 
 def test_pipeline_call_signature_end_to_end(small):
@@ -483,3 +450,27 @@ def test_context_batch_size_is_accepted(small):
     assert torch.equal(outs[0], outs[1])
     with pytest.raises(ValueError):
         pipe(img(), img(), [img()] * F_, [img()] * F_, [img()] * F_, flow, W, H, F_, 2, 3.5, context_batch_size=0)
+
+
+def test_fp32_typed_models_and_latents_match_fp16_run(small):
+    """`weight_dtype: fp32` (reference scripts/inference_video.py:66-69): fp32 parameters, latents and context at the boundary; the
+    kernels round operands to fp16 once (packing / pack_nhwc) -- so on fp16-representable values the fp32-typed run is the fp16 run,
+    bit for bit, returned in fp32."""
+    from mikudance_amd.synth import synth_inputs
+    meta, ref, den, ref_sd, den_sd, t = small
+    lat, rl, emb = (x.half() for x in synth_inputs(4, 16, 16, ctx_len=5, ctx_dim=64, seed=300))
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    out16 = pipe.denoise(lat.cuda(), rl.cuda(), emb.cuda(), 2, 3.5)
+    x = lat[:, :, :2].repeat(2, 1, 1, 1, 1)
+    p16 = den(x.cuda(), torch.tensor(601), encoder_hidden_states=emb.cuda(), return_dict=False)[0]
+    assert out16.dtype == torch.float16 and den.dtype == torch.float16
+    try:
+        ref.float(); den.float()
+        assert den.dtype == torch.float32 and ref.dtype == torch.float32
+        out32 = pipe.denoise(lat.float().cuda(), rl.float().cuda(), emb.float().cuda(), 2, 3.5)
+        p32 = den(x.float().cuda(), torch.tensor(601), encoder_hidden_states=emb.float().cuda(), return_dict=False)[0]
+    finally:
+        ref.half(); den.half()
+    assert out32.dtype == torch.float32 and p32.dtype == torch.float32
+    assert torch.equal(out32.half(), out16) and torch.equal(p32.half(), p16)
+    assert torch.equal(pipe.denoise(lat.cuda(), rl.cuda(), emb.cuda(), 2, 3.5), out16)       # and back
