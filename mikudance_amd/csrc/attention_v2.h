@@ -65,6 +65,20 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
   constexpr bool ONES = (D % 32) != 0;         // room for the ones row in the last O^T tile
   constexpr int DVT = (D + 31) / 32;           // 32-row tiles of O^T
   constexpr int KROWB = D * 2;                 // bytes per K row in LDS (unpadded: DMA image is lane linear)
+  // K-row swizzle (round 4).  A `ds_read_b128` is served in four groups of 16 lanes, conflict-free when the 16 addresses fall
+  // into 16 different 16-byte slots of the 256-byte bank row (MI355X guide, LDS).  The 16 rows a group reads are a complete
+  // residue system mod 16 (kappa maps each group's row set onto itself) and a row is D/8 slots long: 5 at d = 40 (odd: 5r mod 16
+  // already takes 16 values), 10 at d = 80 (2-way conflicts), 20 at d = 160 (4r mod 16: 4-way, a K fragment read costs 16 LDS
+  // cycles instead of 4).  With D/8 = 2^E * odd, slot c of row r is stored at c ^ g(r), g(r) = the top E bits of r mod 16: the
+  // DMA applies the XOR to its per-lane SOURCE address (the LDS image stays lane linear), the fragment read to its LDS address.
+  // SQ_LDS_BANK_CONFLICT per launch: d = 160 1.1e7 -> 0, d = 80 2.7e7 -> 0 (profiles/r04_ab_attention_k_swizzle.log).
+#ifdef A2_NO_KSWIZZLE
+  constexpr int KSW_E = 0;
+#else
+  constexpr int KSW_E = ((D / 8) % 2) ? 0 : ((D / 8) % 4) ? 1 : ((D / 8) % 8) ? 2 : 3;
+#endif
+  static_assert(KSW_E == 0 || (D % 16) != 8, "a k-step shared by K columns and the folded constant: unswizzled flavours only");
+  auto ksw = [](int row) { return KSW_E ? (row >> (4 - KSW_E)) & ((1 << KSW_E) - 1) : 0; };
   constexpr int KBYTES = A2_KT * KROWB;
   constexpr int VBYTES = DVT * 32 * 128;       // V^T rows of 64 keys = 128 B
   constexpr int STAGE = KBYTES + VBYTES;
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
     step[qi] = 0;
     if (q < NKI) {
       const int o = q * 1024 + lane * 16;
-      const int row = o / KROWB, cb = o - row * KROWB;
+      const int row = o / KROWB, cb = (o - row * KROWB) ^ (ksw(row) << 4);
       src0[qi] = reinterpret_cast<const char*>(Kb + (size_t)row * p.ldk) + cb;
       step[qi] = (long)A2_KT * p.ldk * 2;
     } else if (q < NI) {
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
       const int q = qi * NW + wave;
       if (q < NKI) {
         const int o = q * 1024 + lane * 16;
-        const int row = o / KROWB, cb = o - row * KROWB;
+        const int row = o / KROWB, cb = (o - row * KROWB) ^ (ksw(row) << 4);
         const int key = min(j0 + row, p.Lk - 1);
         __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(Kb + (size_t)key * p.ldk) + cb), (lptr_t)(sb + q * 1024), 16, 0, 0);
       } else if (q < NI) {
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
   // K row read by MFMA row index ql: key kappa(ql) = ql with bits 2 and 3 swapped
   const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1);
   const int vsw = (ql >> 1) & 7;  // V^T slot swizzle of row t*32 + ql: ((row >> 1) & 7), 32 | row offset keeps it
+  const int kswz = ksw(krow);     // K slot swizzle of rows krow and 32 + krow
   int stage = 0;
   for (int it = 0; it < ntiles; ++it) {
     const int j0 = it * A2_KT;
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          const char* kp = ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2;
+          const char* kp = ks + (sub * 32 + krow) * KROWB + (((k * 2 + hi) ^ kswz) << 4);
           if (FOLD && k == KS - 1) kp = hi ? smem + CONST_OFF + sub * 32 * KROWB : kp;
           kfr[sub][k] = *reinterpret_cast<const half8_t*>(kp);
         }
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        const char* kp = ks + (sub * 32 + krow) * KROWB + (k * 16 + hi * 8) * 2;
+        const char* kp = ks + (sub * 32 + krow) * KROWB + (((k * 2 + hi) ^ kswz) << 4);
         if (FOLD && k == KS - 1) kp = hi ? smem + CONST_OFF + sub * 32 * KROWB : kp;   // k-slots D.. of every key: {1,0,..,0}
         const half8_t kf = *reinterpret_cast<const half8_t*>(kp);
 #ifdef A2_SETPRIO
