@@ -254,7 +254,9 @@ def _attn_ref(q, k, v, B, H, D, Lq, Lk, kv_index=None):
 
 
 @pytest.mark.parametrize("D,Lq,Lk", [(8, 256, 256), (16, 64, 64), (32, 16, 16), (32, 4, 4), (40, 200, 333), (80, 130, 64),
-                                     (160, 144, 144), (64, 33, 257), (40, 576, 576)])
+                                     (160, 144, 144), (64, 33, 257), (40, 576, 576),
+                                     # fast path (Lk % 8 == 0) with a ragged last key tile at every K-row swizzle width (D/8 = 2, 4, 8, 10, 20 slots)
+                                     (16, 40, 72), (32, 50, 136), (64, 100, 200), (80, 100, 200), (160, 70, 136)])
 def test_attention_self(dev, D, Lq, Lk):
     B, H = 2, 8
     q, k, v = rnd(B * Lq, H * D, seed=40), rnd(B * Lk, H * D, seed=41), rnd(B * Lk, H * D, seed=42)
