@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 // The lane-per-query kernel above is VALU bound (PMC on MI355X, d = 40: VALU 90 % busy at 3.9 TB/s: ~580 VALU instructions
 // per (pixel, head)).  Here ONE WAVE owns a (pixel, head) unit and the two small products run on the matrix core, in QB x QB
 // blocks of 16 keys x 16 queries (QB = 1: F <= 16, QB = 2: F <= 32 -- the 30-frame windows of BASELINE configs[4]):
-//   S^T[key][query] = K Q^T   v_mfma_f32_16x16x32_f16, A = K fragment (LDS, ds_read_b128), B = Q fragment (global -> registers,
-//                             fetched before the K/V staging is issued), ceil(D / 32) steps, k-slots past D zero filled
+//   S^T[key][query] = K Q^T   v_mfma_f32_16x16x32_f16, A = K fragment, B = Q fragment (both LDS, ds_read_b128), ceil(D / 32) steps,
+//                             k-slots past D zero filled
 //   softmax over keys         a lane holds keys 16 kb + 4g .. 4g+3 of query 16 qb + m (g = lane / 16, m = lane % 16): in-lane steps
 //                             + 2 lane exchanges (xor 16, xor 32) for the maximum and for the sum
 //   O^T[d][query] = V^T P^T   v_mfma_f32_16x16x16_f16 (one per key block, accumulated): the S^T accumulator layout IS the B operand
@@ -162,9 +162,25 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 // Frames >= F are clamped for the loads, masked as keys (-inf) and not stored as queries.  The LDS image keeps the DMA's lane
 // linear order but every frame row carries one extra 16-byte slot, so the 16 frame rows a fragment read touches start 16 bytes
 // apart modulo the 256-byte bank period (unpadded rows of PB * HG * D * 2 = 1280 bytes would all start in the same bank).
+//
+// Round 4, the memory side (stream-by-stream ablation on MI355X, profiles/r04_ab_temporal_q_and_o_through_lds.log: with the arithmetic
+// stripped the kernel ran at the same 4.3 TB/s, K + V alone moved at 5.9 TB/s, Q alone at 2.0, the output at 2.7):
+//   * Q comes in like K and V, as whole frame rows by direct-to-LDS DMA (the fragment loads straight from global memory touched 16
+//     rows x 64 bytes per instruction), three images back to back, the lanes past the last 16-byte chunk switched off instead of
+//     rounding each image to the DMA's 1-KiB rows;
+//   * at d <= 80 the output leaves through the Q image (a unit's Q columns are dead once its scores exist): the accumulator layout
+//     gives a lane 8 bytes and a wave 32-byte runs per row; from LDS every store is a 16-byte piece of a whole row;
+//   * 48 KiB of LDS per workgroup at most -> one pixel x 8 heads at d = 40 (31 KiB, 5 workgroups per CU).
+// Same box, F = 16: 0.183 -> 0.152 ms at 96 x 96 (5.0 TB/s), 0.094 -> 0.077 at 48 x 48, 0.045 -> 0.034 at 24 x 24; F = 30 at
+// 128 x 128: 0.715 -> 0.594 ms.  -DTA_Q_REGISTERS builds the previous form (A/B only).
 template <int D, int QB>
 __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams p) {
   constexpr int NKS = (D + 31) / 32, NT = (D + 15) / 16, MAXU = QB == 1 ? 4 : 2;
+#ifdef TA_Q_REGISTERS
+  constexpr bool O_LDS = false;
+#else
+  constexpr bool O_LDS = D <= 80;                      // d = 160 workgroups hold two units: the extra barrier costs more than the 8-byte stores
+#endif
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,6 +197,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
   for (int b = 0; b < QB; ++b) fm[b] = min(16 * b + m, p.F - 1);
   const int nunit = p.PB * p.HG;                       // <= 4 * MAXU (launcher); wave w owns units w, w + 4, ...
 
+#ifdef TA_Q_REGISTERS
   // ---- Q fragments of this wave's units: global -> registers, in flight while K / V are staged
   half8_t qf[MAXU][QB][NKS];
 #pragma unroll
@@ -201,13 +218,21 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
       }
     }
   }
+#endif
 
-  // ---- stage K and V: chunk c -> (frame j, slot); slot < PB * cw8: (pixel, 16-byte column chunk), the last slot is padding
+  // ---- stage Q, K and V: chunk c -> (frame j, slot); slot < PB * cw8: (pixel, 16-byte column chunk), the last slot is padding
   const int spr = p.PB * cw8 + 1;                      // 16-byte slots per frame row
   const int RS = spr * 16;                             // frame row stride in bytes
   const int nchunk = p.F * spr;
+#ifdef TA_Q_REGISTERS
   const int region = ((nchunk * 16 + 1023) >> 10) << 10;
   for (int c = t; c < (region >> 4); c += 256) {
+#else
+  // the three images back to back, no rounding to the DMA's 1-KiB rows: the lanes past the last chunk are switched off instead (a
+  // DMA lane writes M0 + 16 * lane only if it is active), which is what lets a fifth workgroup fit on the CU at d = 40
+  const int region = nchunk * 16;
+  for (int c = t; c < nchunk; c += 256) {
+#endif
     const int cl = min(c, nchunk - 1);
     const int j = cl / spr;
     int sl = cl - j * spr;
@@ -219,11 +244,17 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
     const int cbase = __builtin_amdgcn_readfirstlane(c) << 4;
     __builtin_amdgcn_global_load_lds((gptr_t)(p.K + row * p.ldk + col0 + cc * 8), (lptr_t)(smem + cbase), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(p.V + row * p.ldv + col0 + cc * 8), (lptr_t)(smem + region + cbase), 16, 0, 0);
+#ifndef TA_Q_REGISTERS
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.Q + row * p.ldq + col0 + cc * 8), (lptr_t)(smem + 2 * region + cbase), 16, 0, 0);
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const char* Ks = smem;
   const char* Vs = smem + region;
+#ifndef TA_Q_REGISTERS
+  const char* Qs = smem + 2 * region;
+#endif
   const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;   // ds_bpermute addresses of the lanes holding the other keys of query m
   auto xch = [](int addr, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); };
 
@@ -235,6 +266,17 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
     const int gp = pg + pl;
     if (gp >= npix) break;
     const int ubase = (pl * CW + hl * D) * 2;          // byte offset of this unit's columns inside a frame row
+#ifndef TA_Q_REGISTERS
+    half8_t qfu[QB][NKS];                              // B operand: query 16 qb + m, k-slots 32 s + 8 g .. + 7 (zero past D)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int s2 = 0; s2 < NKS; ++s2) {
+        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (32 * s2 + 8 * g < D) v = *reinterpret_cast<const half8_t*>(Qs + fm[qb] * RS + ubase + (32 * s2 + 8 * g) * 2);
+        qfu[qb][s2] = v;
+      }
+#endif
     // ---- S^T = K Q^T, QB x QB blocks
     floatx4 sacc[QB][QB];
 #pragma unroll
@@ -248,7 +290,11 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
         half8_t kf = {0, 0, 0, 0, 0, 0, 0, 0};
         if (32 * s + 8 * g < D) kf = *reinterpret_cast<const half8_t*>(Ks + fm[kb] * RS + ubase + (32 * s + 8 * g) * 2);
 #pragma unroll
+#ifdef TA_Q_REGISTERS
         for (int qb = 0; qb < QB; ++qb) sacc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][qb][s], sacc[kb][qb], 0, 0, 0);
+#else
+        for (int qb = 0; qb < QB; ++qb) sacc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qfu[qb][s], sacc[kb][qb], 0, 0, 0);
+#endif
       }
     }
     // ---- softmax over the keys 16 kb + 4g + r of query 16 qb + m
@@ -311,10 +357,28 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
         for (int kb = 0; kb < QB; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[kb], pb[qb][kb], o, 0, 0, 0);
         if (16 * qb + m < p.F && db < D) {
           const half4_t ov = {(half_t)(o[0] * inv[qb]), (half_t)(o[1] * inv[qb]), (half_t)(o[2] * inv[qb]), (half_t)(o[3] * inv[qb])};
-          *reinterpret_cast<half4_t*>(op[qb] + db) = ov;
+          if constexpr (O_LDS)   // into this unit's own (dead) columns of the Q image: the rows leave the workgroup as whole 16-byte pieces below
+            *reinterpret_cast<half4_t*>(smem + 2 * region + fm[qb] * RS + ubase + db * 2) = ov;
+          else
+            *reinterpret_cast<half4_t*>(op[qb] + db) = ov;
         }
       }
     }
+  }
+  if constexpr (O_LDS) {
+  // ---- O leaves through the Q image: 16-byte pieces of whole frame rows (the accumulator layout gives a lane 8 bytes and a wave
+  // 32-byte runs; written straight from it the output moved at 2.7 TB/s, profiles/r04_ab_temporal_q_and_o_through_lds.log)
+  __syncthreads();
+  for (int c = t; c < nchunk; c += 256) {
+    const int j = c / spr, sl = c - j * spr;
+    if (sl == spr - 1) continue;                       // padding slot
+    const int pl = sl / cw8, cc = sl - pl * cw8;
+    const int gp = pg + pl;
+    if (gp >= npix) continue;
+    const int b = gp / p.HW, pix = gp - b * p.HW;
+    const size_t row = ((size_t)b * p.F + j) * p.HW + pix;
+    *reinterpret_cast<half8_t*>(p.O + row * p.ldo + col0 + cc * 8) = *reinterpret_cast<const half8_t*>(smem + 2 * region + (c << 4));
+  }
   }
 }
 
@@ -323,17 +387,33 @@ static void launch_temporal_mfma(TemporalParams p, hipStream_t st) {
   // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds the LDS budget
   // (48 KiB for F <= 16, swept 24 .. 90; 80 KiB for the 17 .. 32-frame windows, whose images are twice as tall); then as many
   // pixels as fit, at most 4 * MAXU (pixel, head) units (MAXU = 4 / 2 per wave)
+#ifdef TA_Q_REGISTERS
+  constexpr int NIMG = 2;
   const size_t cap = (size_t)(QB == 1 ? 48 : 80) * 1024;
+#else
+  constexpr int NIMG = 3;                              // Q, K, V images
+#ifndef TA_LDS_CAP
+#define TA_LDS_CAP 48
+#endif
+#ifndef TA_LDS_CAP2
+#define TA_LDS_CAP2 48
+#endif
+  const size_t cap = (size_t)(QB == 1 ? TA_LDS_CAP : TA_LDS_CAP2) * 1024;
+#endif
   constexpr int UNITS = QB == 1 ? 16 : 8;
   int HG = p.H;
-  auto lds = [&](int hg, int pb) { return (size_t)2 * ((((size_t)p.F * (pb * hg * D * 2 + 16)) + 1023) / 1024 * 1024); };
+#ifdef TA_Q_REGISTERS
+  auto lds = [&](int hg, int pb) { return (size_t)NIMG * ((((size_t)p.F * (pb * hg * D * 2 + 16)) + 1023) / 1024 * 1024); };
+#else
+  auto lds = [&](int hg, int pb) { return (size_t)NIMG * p.F * (pb * hg * D * 2 + 16); };
+#endif
   while (HG > 1 && lds(HG, 1) > cap) HG >>= 1;
   int PB = UNITS / HG;
   while (PB > 1 && lds(HG, PB) > cap) --PB;
   p.HG = HG; p.PB = PB;
   const size_t smem = lds(HG, PB);
   const int grid = cdiv((long)p.NB * p.HW, PB) * (p.H / HG);
-  md_ensure_dynamic_lds<temporal_attn_mfma_kernel<D, QB>>(96 * 1024);
+  md_ensure_dynamic_lds<temporal_attn_mfma_kernel<D, QB>>(128 * 1024);
   hipLaunchKernelGGL((temporal_attn_mfma_kernel<D, QB>), dim3(grid), dim3(256), smem, st, p);
 }
 
@@ -359,7 +439,12 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.NB = NB; p.F = F; p.HW = HW; p.H = H; p.D = D;
   p.scale_log2 = scale * 1.4426950408889634f;
-  if ((D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31)) {
+#ifdef TA_Q_REGISTERS
+  const bool o16 = true;
+#else
+  const bool o16 = (reinterpret_cast<uintptr_t>(O) & 15) == 0;      // the matrix-core kernel stores 16-byte pieces
+#endif
+  if ((D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31) && o16) {
     hipStream_t st = (hipStream_t)stream;
     if (F <= 16) {
       if (D == 40) launch_temporal_mfma<40, 1>(p, st);
