@@ -394,6 +394,103 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
   }
 }
 
+// C = 320 (the 96 x 96 level: half of the clip's LayerNorm time).  A 640-byte row fills 40 of a wave's 64 lanes.  Here a wave owns EIGHT
+// consecutive rows = 320 16-byte chunks = five full-wave loads of one contiguous 5-KiB block: chunk q = 64 i + lane belongs to row
+// q / 40.  Row statistics are accumulated per lane into the (at most three) rows a load index can touch and reduced across the wave
+// as above; same arithmetic per element.  Same box: 0.081-0.083 -> 0.077-0.080 ms at M = 294912 (4.6 -> 4.8 TB/s), 0.034 -> 0.032 at
+// M = 147456; a persistent form that requests a wave's next block before reducing the current one needs 168 registers and runs at
+// 0.097-0.100 ms (profiles/r04_ab_layernorm_c320.log).
+__global__ __launch_bounds__(256) void layernorm320_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, half_t* __restrict__ y2,
+                                                           const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                           const half_t* __restrict__ add, int M, float eps, int add_mode, int add_row_begin,
+                                                           int rows_per_frame, int frames) {
+  constexpr int C = 320, CCH = 40, R = 8, NI = 5;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
+  int ri[NI], ci[NI];
+  float v[NI][8];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = i * 64 + lane;
+    ri[i] = q / CCH;
+    ci[i] = q - ri[i] * CCH;
+    const int row = min(row0 + ri[i], M - 1);
+    const half8_t h = *reinterpret_cast<const half8_t*>(x + (size_t)row * C + ci[i] * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = (float)h[e];
+  }
+  float mu[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mu[r] = rstd[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[i][e];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r >= (i * 64) / CCH && r <= (i * 64 + 63) / CCH) mu[r] += ri[i] == r ? s : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) mu[r] += __shfl_xor(mu[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < R; ++r) mu[r] /= (float)C;
+  float mi[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r >= (i * 64) / CCH && r <= (i * 64 + 63) / CCH) m = ri[i] == r ? mu[r] : m;
+    mi[i] = m;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[i][e] - m;
+      sq += d * d;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r >= (i * 64) / CCH && r <= (i * 64 + 63) / CCH) rstd[r] += ri[i] == r ? sq : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(rstd[r] / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = row0 + ri[i];
+    if (row >= M) continue;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r >= (i * 64) / CCH && r <= (i * 64 + 63) / CCH) rs = ri[i] == r ? rstd[r] : rs;
+    const half8_t g = *reinterpret_cast<const half8_t*>(gamma + ci[i] * 8);
+    const half8_t bt = *reinterpret_cast<const half8_t*>(beta + ci[i] * 8);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[i][e] - mi[i]) * rs * (float)g[e] + (float)bt[e]);
+    norm_store(reinterpret_cast<half8_t*>(y + (size_t)row * C + ci[i] * 8), o);
+    if (y2) {
+      const half_t* addp = nullptr;
+      if (add_mode == 1 && row >= add_row_begin) addp = add + (size_t)(row - add_row_begin) * C;  // bank rows
+      if (add_mode == 2) addp = add + (size_t)((row / rows_per_frame) % frames) * C;            // positional encoding of the frame
+      half8_t o2 = o;
+      if (addp) {
+        const half8_t a = *reinterpret_cast<const half8_t*>(addp + ci[i] * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o2[e] = (half_t)((float)o[e] + (float)a[e]);  // fp16 n + fp16 bank, one rounding
+      }
+      norm_store(reinterpret_cast<half8_t*>(y2 + (size_t)row * C + ci[i] * 8), o2);
+    }
+  }
+}
+
 extern "C" int md_layernorm_f16(const void* x, void* y, void* y2, const void* gamma, const void* beta, const void* add, int M, int C, float eps,
                                 int add_mode, int add_row_begin, int rows_per_frame, int frames, void* stream) {
   MD_CHECK_ARG(C % 8 == 0 && C <= 8 * 64 * LN_MAXC, "md_layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXC);
@@ -401,6 +498,14 @@ extern "C" int md_layernorm_f16(const void* x, void* y, void* y2, const void* ga
   MD_CHECK_ARG(add_mode != 2 || (rows_per_frame > 0 && frames > 0), "md_layernorm: add_mode 2 needs rows_per_frame and frames");
   const dim3 grid(cdiv(M, 4 * LN_R)), block(256);
   hipStream_t st = (hipStream_t)stream;
+#ifndef LN_NO_320
+  if (C == 320) {
+    hipLaunchKernelGGL(layernorm320_kernel, dim3(cdiv(M, 32)), block, 0, st, (const half_t*)x, (half_t*)y, (half_t*)y2, (const half_t*)gamma,
+                       (const half_t*)beta, (const half_t*)add, M, eps, add_mode, add_row_begin, rows_per_frame, frames);
+    MD_CHECK_LAUNCH("md_layernorm");
+    return MD_OK;
+  }
+#endif
 #define LN_LAUNCH(MC)                                                                                                                           \
   hipLaunchKernelGGL(layernorm_kernel<MC>, grid, block, 0, st, (const half_t*)x, (half_t*)y, (half_t*)y2, (const half_t*)gamma, (const half_t*)beta, \
                      (const half_t*)add, M, C, eps, add_mode, add_row_begin, rows_per_frame, frames)

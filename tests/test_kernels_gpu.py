@@ -191,7 +191,7 @@ def test_groupnorm(dev, B, HW, C, silu, eps):
     close(ops.groupnorm(x.to(dev), g.to(dev), b.to(dev), 32, eps, silu), ref, what="groupnorm")
 
 
-@pytest.mark.parametrize("M,C", [(10, 64), (301, 320), (64, 1280), (5, 256)])
+@pytest.mark.parametrize("M,C", [(10, 64), (301, 320), (64, 1280), (5, 256), (7, 320), (2053, 320)])
 def test_layernorm_and_adds(dev, M, C):
     x = rnd(M, C, seed=33) * 3 + 1
     g, b = (1 + 0.1 * rnd(C, seed=34).float()).half(), rnd(C, seed=35)
