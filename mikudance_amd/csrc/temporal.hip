@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalParams p) {
 //                             layout (keys 4g .. 4g+3 of query m), A = V^T tile gathered from the frame-major LDS image with 2-byte
 //                             reads, ceil(D / 16) tiles
 // Frames >= F are clamped for the loads, masked as keys (-inf) and not stored as queries.  The LDS image keeps the DMA's lane
-// linear order but every frame row carries one extra 16-byte slot, so the 16 frame rows a fragment read touches start 16 bytes
-// apart modulo the 256-byte bank period (unpadded rows of PB * HG * D * 2 = 1280 bytes would all start in the same bank).
+// linear order but every frame row carries one extra 16-byte slot: the row pitch is an odd number of slots (41 / 81), so the 16 frame
+// rows of one k-slice start in 16 different slots of the 256-byte bank row (unpadded rows of 640 / 1280 bytes would all start in the
+// same one).  A ds_read_b128 lane group mixes two k-slices, which leaves 2-way conflicts (3 % of the cycles at d = 40; a pitch of
+// 2 mod 4 slots would remove them: tests/test_lds_layouts_cpu.py, profiles/r04_pmc_temporal_final.md).
 //
 // Round 4, the memory side (stream-by-stream ablation on MI355X, profiles/r04_ab_temporal_q_and_o_through_lds.log: with the arithmetic
 // stripped the kernel ran at the same 4.3 TB/s, K + V alone moved at 5.9 TB/s, Q alone at 2.0, the output at 2.7):
@@ -384,9 +386,9 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
 
 template <int D, int QB>
 static void launch_temporal_mfma(TemporalParams p, hipStream_t st) {
-  // heads per workgroup: all of them unless one pixel's K + V image (2 * F rows of HG * D * 2 + 16 bytes) exceeds the LDS budget
-  // (48 KiB for F <= 16, swept 24 .. 90; 80 KiB for the 17 .. 32-frame windows, whose images are twice as tall); then as many
-  // pixels as fit, at most 4 * MAXU (pixel, head) units (MAXU = 4 / 2 per wave)
+  // heads per workgroup: all of them unless one pixel's Q + K + V images (3 * F rows of HG * D * 2 + 16 bytes) exceed the LDS budget
+  // (48 KiB, swept 16 .. 128 at F = 16 and 48 / 64 / 100 at F = 30: profiles/r04_ab_temporal_q_and_o_through_lds.log); then as many
+  // pixels as fit, at most 4 * MAXU (pixel, head) units (MAXU = 4 / 2 per wave).  d = 40 / 80 / 160 at F <= 16: 8 / 4 / 2 heads of one pixel
 #ifdef TA_Q_REGISTERS
   constexpr int NIMG = 2;
   const size_t cap = (size_t)(QB == 1 ? 48 : 80) * 1024;
@@ -442,7 +444,8 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
 #ifdef TA_Q_REGISTERS
   const bool o16 = true;
 #else
-  const bool o16 = (reinterpret_cast<uintptr_t>(O) & 15) == 0;      // the matrix-core kernel stores 16-byte pieces
+  // the matrix-core kernel moves every operand and the output as 16-byte pieces
+  const bool o16 = ((reinterpret_cast<uintptr_t>(O) | reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
 #endif
   if ((D == 40 || D == 80 || D == 160) && (long)NB * HW < (1L << 31) && o16) {
     hipStream_t st = (hipStream_t)stream;
