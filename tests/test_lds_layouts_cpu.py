@@ -145,6 +145,7 @@ def test_temporal_pitch_two_mod_four_would_be_conflict_free():
     """Not built: the row pitches (in 16-byte slots) that make the K / Q fragment reads conflict-free under the real lane groups are the
     ones = 2 (mod 4) -- e.g. 42 instead of 41 slots at d = 40 (one pixel x 8 heads).  Kept as the arithmetic behind the note in
     csrc/temporal.hip and profiles/r04_pmc_temporal_final.md."""
-    good = [P for P in range(16) if conflict_free_b128(lambda lane, P=P: (lane & 15) * P * 16 + (lane >> 4) * 16)]
+    # pitch P + 32 slots: the same residue mod 16, rows far enough apart that two lanes never name the same address (a broadcast)
+    good = [P for P in range(16) if conflict_free_b128(lambda lane, P=P: (lane & 15) * (P + 32) * 16 + (lane >> 4) * 16)]
     assert good == [2, 6, 10, 14]
     assert conflict_ways_b128(lambda lane: (lane & 15) * 41 * 16 + (lane >> 4) * 16) == 2      # today's pitch
