@@ -40,6 +40,9 @@
 #ifndef WS_RES_DEPTH
 #define WS_RES_DEPTH 4         // residual tiles in flight per store wave
 #endif
+#ifndef WS_RES_DEPTH_640
+#define WS_RES_DEPTH_640 WS_RES_DEPTH   // ... of the K = 640 flavour (2 pieces per lane and tile instead of 5: the registers allow more)
+#endif
 
 struct WsParams {
   const half_t* A;
@@ -78,7 +81,8 @@ struct WsCfg {
   static constexpr int PD = KS <= 10 ? 3 : 6;     // A fragments in flight per compute wave (register budget: 256 per wave)
   static_assert(DPT % 2 == 0 && CHUNKS % 128 == 0, "tile must split evenly over the loader / store waves");
   static_assert(NR >= 3 && (NR - 2) * TPR * PER <= 63, "ring depth / vmcnt immediate");
-  static_assert(WS_RES_DEPTH % TPR == 0, "residual buffers are indexed statically per unrolled round");
+  static constexpr int RES_DEPTH = KS == 20 ? WS_RES_DEPTH_640 : WS_RES_DEPTH;
+  static_assert(RES_DEPTH % TPR == 0, "residual buffers are indexed statically per unrolled round");
 };
 
 template <int CPR>
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         cp[i] = p.C + (size_t)(stream * TR + prow[i]) * p.ldc + n0 + pcol[i];
         rp[i] = RES ? p.residual + (size_t)(stream * TR + prow[i]) * p.ldr + n0 + pcol[i] : nullptr;
       }
-      constexpr int RD = RA ? 2 : WS_RES_DEPTH;       // residual tiles in flight per store wave (fewer when the row-broadcast term
+      constexpr int RD = RA ? 2 : Cfg::RES_DEPTH;     // residual tiles in flight per store wave (fewer when the row-broadcast term
                                                       // also lives in registers: 256 VGPRs per wave)
       static_assert(RD % TPR == 0, "residual buffers are indexed statically per unrolled round");
       constexpr int UNR = RD / TPR;                   // rounds per unrolled loop body
@@ -305,7 +309,11 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       auto fetch_res = [&](half8_t (&dst)[SPL]) {     // the next tile of this stream in order; rp[] advances
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
+#if defined(WS_ABL_RES) && WS_ABL_RES == 2              // diagnostic build (results wrong by construction): the adds without the loads
+          dst[i] = half8_t{1, 1, 1, 1, 1, 1, 1, 1};
+#else
           dst[i] = *reinterpret_cast<const half8_t*>(rp[i]);
+#endif
           rp[i] += rstep;
         }
       };
@@ -346,8 +354,12 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
             for (int j = 0; j < 8; ++j) v[j] += raf[i][j];
           }
           if constexpr (RES) {
+#if defined(WS_ABL_RES) && WS_ABL_RES == 1              // diagnostic build: the loads without the adds
+            asm volatile("" ::"v"(rs[i]));
+#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)rs[i][j];
+#endif
           }
           half8_t o;
 #pragma unroll
