@@ -95,6 +95,35 @@ int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const void* gamma,
 int md_layernorm_f16(const void* x, void* y, void* y2, const void* gamma, const void* beta, const void* add, int M,
                      int C, float eps, int add_mode, int add_row_begin, int rows_per_frame, int frames, void* stream);
 
+/* LayerNorm FOLDED into the Linear that consumes it: C = epi(LayerNorm(A; gamma, beta, eps) . W^T + bias) computed from the RAW rows
+ * of A, the normalised tensor never touching HBM.  The caller folds once per layer (mikudance_amd/packing.py ln_fold):
+ *   Wf[n][k] = fp16(gamma[k] W[n][k]),   sc = fp32 [2][N]:  sc[0][n] = sum_k Wf[n][k],  sc[1][n] = sum_k beta[k] W[n][k] + bias[n]
+ * and the kernel evaluates rstd_m * (A[m] . Wf[n] - mu_m * sc[0][n]) + sc[1][n] with the exact two-pass (mu, rstd) of each row taken
+ * from the rows as they stream through LDS.  rowadd / rows_per_group as in md_gemm_f16 (the motion module's query-only positional
+ * encoding as a per-frame row term); act = MD_ACT_NONE or MD_ACT_GEGLU (Wf rows in the GEGLU packing, sc in the same row order).
+ * Only the shapes of the W-stationary streaming kernel exist (K = 320 / 640 on >= 32768 rows): md_gemm_ln_plan(M, N, K, act, epi)
+ * returns 1 when this entry point has a kernel for the problem (epi bit 1: rowadd), 0 when the caller has to run md_layernorm_f16 +
+ * md_gemm_f16 on the unfolded weights; md_gemm_ln_f16 itself fails (MD_ERR_ARG) on anything else -- there is no silent fallback.
+ * Replaces norm2 -> attn2.to_q and norm3 -> ff.net.0 (src/models/attention.py:131-157,339-365; src/models/mutual_mix_attention.py:
+ * 203-275) and norms[i] -> to_q / to_k / to_v, ff_norm -> ff.net.0 of the motion module (src/models/motion_module.py:245-272). */
+int md_gemm_ln_plan(int M, int N, int K, int act, int epi);
+int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, void* C, int ldc, int M, int N, int K, float eps,
+                   const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
+
+/* GroupNorm in front of a Linear / 1x1 conv without materialising the normalised tensor.  md_groupnorm_table_f16 runs the statistics
+ * sweep only and writes table = fp32 [B][2][C]: scale[b][c] = rstd * gamma[c], shift[b][c] = beta[c] - mean * scale;
+ * md_gemm_affine_f16 computes C = (A * scale[image] + shift[image], rounded to fp16) . W^T + bias, image = row / rows_per_image,
+ * applying the affine to the rows as they stream through LDS: bit-identical to md_groupnorm_ld_nhwc_f16 (silu = 0, two-sweep form)
+ * followed by md_gemm_f16.  A may be a channel slice (lda >= K).  md_gemm_affine_plan: 1 when the kernel exists for the shape (K = 320 /
+ * 640, >= 32768 rows, rows_per_image % 16 == 0).  Replaces norm -> proj_in of Transformer3DModel / Transformer2DModel
+ * (src/models/transformer_3d.py:60-68,121-137; src/models/transformer_2d.py:296-321) and of the motion module's
+ * TemporalTransformer3DModel (src/models/motion_module.py:121-124,159-170). */
+int md_groupnorm_table_f16(const void* x, int ldx, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
+                           float* table, void* workspace, size_t ws_bytes, void* stream);
+int md_gemm_affine_plan(int M, int N, int K, int rows_per_image);
+int md_gemm_affine_f16(const void* A, int lda, const float* table, int rows_per_image, const void* W, void* C, int ldc, int M, int N,
+                       int K, const void* bias, void* stream);
+
 /* MAN: y = InstanceNorm(x) * (1 + gamma) + beta; gamma_beta is (B, HW, 2C) = [gamma | beta].
  * src/models/man_module.py:23-33. */
 int md_instnorm_spade_f16(const void* x, const void* gamma_beta, void* y, int B, int HW, int C, float eps,

@@ -174,9 +174,40 @@ def _pack_ff(ff, dev, pk, prefix="ff"):
     pk[prefix + "2"], pk[prefix + "2b"] = packing.linear_weight(ff.net[2].weight, dev), packing.vec(ff.net[2].bias, dev)
 
 
-def _run_ff(pk, n, resid, prefix="ff"):
-    g = ops.gemm(n, pk[prefix + "1"], bias=pk[prefix + "1b"], act=ops.ACT_GEGLU)
-    return ops.gemm(g, pk[prefix + "2"], bias=pk[prefix + "2b"], residual=resid)
+# Normalisations that never reach HBM (tests switch this off to compare against the literal operator sequence).  Where the
+# W-stationary streaming GEMM serves the consumer (K = 320 / 640 on >= 32768 tokens: the 96 x 96 and 48 x 48 levels), a LayerNorm is
+# folded into its Linear (md_gemm_ln_f16) and a SiLU-free GroupNorm is applied to the rows inside the GEMM (md_gemm_affine_f16);
+# everywhere else the literal pair of operators runs.  norm1 stays a kernel of its own: its output IS the bank / K-V operand.
+FUSE_NORMS = True
+
+
+def ln_linear(pk, h, norm, lin, bias=None, rowadd=None, rows_per_group=0, act=ops.ACT_NONE, eps=1e-5):
+    """LayerNorm(pk[norm + 'w'], pk[norm + 'b']) -> Linear(pk[lin], pk[bias]) [+ row term] [GEGLU] on the token matrix h."""
+    M, K = h.shape
+    w = pk[lin]
+    if FUSE_NORMS and ops.gemm_ln_plan(M, w.shape[0], K, act, rowadd is not None):
+        fk = lin + ":ln"
+        if fk not in pk:                  # folded once per layer, on first use (only the layers the fused kernel serves pay for it)
+            pk[fk] = packing.ln_fold(w, None if bias is None else pk[bias], pk[norm + "w"], pk[norm + "b"])
+        wf, sc = pk[fk]
+        return ops.gemm_ln(h, wf, sc, eps=eps, rowadd=rowadd, rows_per_group=rows_per_group, act=act)
+    n = ops.layernorm(h, pk[norm + "w"], pk[norm + "b"], eps=eps)
+    return ops.gemm(n, w, bias=None if bias is None else pk[bias], rowadd=rowadd, rows_per_group=rows_per_group, act=act)
+
+
+def gn_linear(x, gamma, beta, eps, w, bias):
+    """GroupNorm(32, eps) (no SiLU) -> 1 x 1 conv / Linear on the tokens of x (B, H, W, C); returns [B*H*W, N]."""
+    B, C = x.shape[0], x.shape[-1]
+    M = x.numel() // C
+    if FUSE_NORMS and ops.gemm_affine_plan(M, w.shape[0], C, M // B):
+        return ops.gemm_affine(x, ops.groupnorm_table(x, gamma, beta, GROUPS, eps), w, bias=bias)
+    return ops.gemm(tokens(ops.groupnorm(x, gamma, beta, GROUPS, eps)), w, bias=bias)
+
+
+def _run_ff(pk, h, norm, prefix="ff"):
+    """h + FeedForward(LayerNorm(h)) (GEGLU)."""
+    g = ln_linear(pk, h, norm, prefix + "1", bias=prefix + "1b", act=ops.ACT_GEGLU)
+    return ops.gemm(g, pk[prefix + "2"], bias=pk[prefix + "2b"], residual=h)
 
 
 class CrossContext:
@@ -283,12 +314,10 @@ class TransformerBlock(_Packed):
         # cross attention to the CLIP tokens
         if zf < B:
             hs = h[zf * L:]
-            n2 = ops.layernorm(hs, pk["n2w"], pk["n2b"])
-            q2 = ops.gemm(n2, pk["q2"])
+            q2 = ln_linear(pk, hs, "n2", "q2")
             a2 = ops.attention(q2, kv2[0], kv2[1], B - zf, H, D, L, cross.lk, kv_stride=cross.lpad, kv_index=cross.index[zf:])
             ops.gemm(a2, pk["o2"], bias=pk["o2b"], residual=hs, out=hs)    # in place: each element is read and written by one thread
-        n3 = ops.layernorm(h, pk["n3w"], pk["n3b"])
-        return _run_ff(pk, n3, h)
+        return _run_ff(pk, h, "n3")
 
 
 class SpatialTransformer(_Packed):
@@ -312,8 +341,7 @@ class SpatialTransformer(_Packed):
         pk = self.packed()
         B, Hh, Ww, C = x.shape
         blk = self.transformer_blocks[0]
-        h = ops.groupnorm(x, pk["nw"], pk["nb"], GROUPS, 1e-6)
-        h = ops.gemm(tokens(h), pk["pi"], bias=pk["pib"])
+        h = gn_linear(x, pk["nw"], pk["nb"], 1e-6, pk["pi"], pk["pib"])
         h = blk(h, B, Hh * Ww, cross)
         if blk.ref_mode == "write" and blk.stop_after_bank:
             return x
@@ -398,18 +426,15 @@ class MotionModule(_Packed):
             raise ValueError(f"window of {f} frames exceeds the positional-encoding table ({self.max_len})")
         _, Hh, Ww, C = x.shape
         HW, H = Hh * Ww, self.heads
-        h = ops.groupnorm(x, pk["nw"], pk["nb"], GROUPS, 1e-6)
-        h = ops.gemm(tokens(h), pk["pi"], bias=pk["pib"])
+        h = gn_linear(x, pk["nw"], pk["nb"], 1e-6, pk["pi"], pk["pib"])
         for i in range(2):
-            n = ops.layernorm(h, pk[f"n{i}w"], pk[f"n{i}b"])
             tab = pk.get(("peq", i, nb, f))
             if tab is None:
                 tab = pk[("peq", i, nb, f)] = pk[f"peq{i}"][:f].repeat(nb, 1).contiguous()       # one row per (clip-half, frame)
-            qkv = ops.gemm(n, pk[f"qkv{i}"], rowadd=tab, rows_per_group=HW)
+            qkv = ln_linear(pk, h, f"n{i}", f"qkv{i}", rowadd=tab, rows_per_group=HW)
             a = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, f, HW, H, C // H)
             h = ops.gemm(a, pk[f"o{i}"], bias=pk[f"o{i}b"], residual=h)
-        n = ops.layernorm(h, pk["fnw"], pk["fnb"])
-        h = _run_ff(pk, n, h)
+        h = _run_ff(pk, h, "fn")
         if out is not None:
             ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x), out=tokens(out))
             return out

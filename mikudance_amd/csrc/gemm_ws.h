@@ -57,7 +57,31 @@ struct WsParams {
   int groups;        // column groups G
   int streams;       // row streams (workgroups per column group)
   int spx;           // row streams per XCD
+  // prologue flavours (PRO != 0): a normalisation of the A rows that never exists in HBM
+  const float* lnf;  // PRO_LNF: [2][N] fp32 -- s[n] = sum_k W'[n][k] and c[n] = sum_k beta[k] W[n][k] + bias[n] of the folded LayerNorm
+  float eps;         // PRO_LNF: LayerNorm epsilon
+  const float* aff;  // PRO_AFF: [M / rows_per_image][2][K] fp32 -- per (image, input channel) scale then shift (GroupNorm apply)
+  int rows_per_image;
 };
+
+// Prologues.  Both rest on the fact that a stage of this kernel holds WHOLE rows of A (all of K) in LDS before the matrix core reads it.
+//   PRO_LNF  LayerNorm folded into the Linear that consumes it (norm2 -> attn2.to_q, norm3 / ff_norm -> ff.net.0, the motion module's
+//            norms -> q|k|v: reference src/models/attention.py:131-157,339-364, src/models/motion_module.py:229-272).  With
+//            W'[n][k] = fp16(gamma[k] W[n][k]),  s[n] = sum_k W'[n][k],  c[n] = sum_k beta[k] W[n][k] + bias[n]:
+//                LN(x) . W^T + bias = rstd * (x . W'^T - mu * s) + c
+//            so the GEMM runs on the RAW rows and the normalised tensor is never written or read (4 bytes per element and a launch
+//            saved per LayerNorm).  The loader waves, which own eight rows of every tile they have just DMA'd, compute the exact two-pass
+//            (mu, rstd) of their rows from the landed stage and leave a = rstd, b = -mu * rstd in a small LDS ring; the epilogue applies
+//            a * acc + (b * s + c) -- in the store waves for the plain flavours, in the COMPUTE waves for GEGLU (whose memory waves are
+//            bound by the GELU arithmetic and now skip the bias add).  s is summed from the ROUNDED W', so x . W'^T - mu * s is exactly
+//            sum_k (x_k - mu) W'[n][k]: the fold is as insensitive to the row mean as the two-pass LayerNorm it replaces.
+//   PRO_AFF  per-(image, channel) affine x * scale + shift applied to the landed stage IN PLACE, one rounding to fp16 -- GroupNorm's
+//            apply sweep in front of proj_in (reference src/models/transformer_3d.py:60-68,121-137, src/models/motion_module.py:121-124,
+//            159-170) with scale = rstd * gamma, shift = beta - mean * scale from md_groupnorm_table_f16: bit-identical to
+//            gn_apply_kernel followed by this GEMM, minus the 4 bytes per element the normalised tensor cost.  The table of the lane's
+//            columns lives in registers and changes with the image, so PRO_AFF streams walk CONTIGUOUS row blocks (a stream meets at
+//            most ceil(rows per stream / rows per image) + 1 images) instead of the interleaved tiles of the other flavours.
+enum { PRO_NONE = 0, PRO_LNF = 1, PRO_AFF = 2 };
 
 template <int KS, int CB, int TPR>
 struct WsCfg {
@@ -71,11 +95,12 @@ struct WsCfg {
   static constexpr int CS_LD = GC + 4;            // fp32 staging pitch (floats): rows shift by 4 banks
   static constexpr int CSTAGE = TR * CS_LD * 4;   // one staging tile; 2 * TPR of them (double buffered rounds)
   static constexpr int OSTAGE = GEGLU_CFG ? 2 * 2048 : 0;   // GEGLU: fp16 pieces finished by the loader waves, shipped by the store waves
-  static constexpr int NR_FIT = (160 * 1024 - 2 * TPR * CSTAGE - OSTAGE) / RSTAGE;
+  static constexpr int SSTAGE = 4 * TPR * TR * 8;           // PRO_LNF: (a, b) per row, 4 rounds deep (written in round r-1, read in r and r+1)
+  static constexpr int NR_FIT = (160 * 1024 - 2 * TPR * CSTAGE - OSTAGE - SSTAGE) / RSTAGE;
   static constexpr int NR = NR_FIT > 12 ? 12 : NR_FIT;       // ring depth in rounds
   static constexpr int DPT = STAGE / 1024;        // DMA wave-instructions per tile
   static constexpr int PER = DPT / 2;             // ... per loader wave
-  static constexpr int SMEM = NR * RSTAGE + 2 * TPR * CSTAGE + OSTAGE;
+  static constexpr int SMEM = NR * RSTAGE + 2 * TPR * CSTAGE + OSTAGE + SSTAGE;
   static constexpr int CHUNKS = TR * GC / 8;      // 16-byte output pieces per tile
   static constexpr int SPL = CHUNKS / 128;        // ... per lane of the two store waves
   static constexpr int PD = KS <= 10 ? 3 : 6;     // A fragments in flight per compute wave (register budget: 256 per wave)
@@ -95,6 +120,7 @@ struct WsGegluPiece {
   int row, hcol;            // staging row, staging column of h (g sits 32 columns further)
   float bh[8], bg[8];
 };
+template <bool BIAS = true>    // BIAS = false (PRO_LNF): the compute waves have already applied the folded LayerNorm, bias included
 __device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, const WsGegluPiece& q) {
   const float* s = cs + q.row * cs_ld + q.hcol;
   const floatx4 h0 = *reinterpret_cast<const floatx4*>(s), h1 = *reinterpret_cast<const floatx4*>(s + 4);
@@ -102,19 +128,21 @@ __device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, co
   half8_t o;
   float2_t gl[4];                         // pairs: the GELU polynomial runs on packed fp32, the four chains of a piece side by side
 #pragma unroll
-  for (int j = 0; j < 4; ++j) gl[j] = float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]};
+  for (int j = 0; j < 4; ++j) gl[j] = BIAS ? float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]} : float2_t{g0[j], g1[j]};
   gelu_fast2_x<4>(gl);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    o[j] = (half_t)((h0[j] + q.bh[j]) * gl[j].x);
-    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gl[j].y);
+    o[j] = (half_t)((BIAS ? h0[j] + q.bh[j] : h0[j]) * gl[j].x);
+    o[j + 4] = (half_t)((BIAS ? h1[j] + q.bh[j + 4] : h1[j]) * gl[j].y);
   }
   return o;
 }
 
-template <int KS, int CB, int TPR, bool RES, bool RA, bool GEGLU = false>
+template <int KS, int CB, int TPR, bool RES, bool RA, bool GEGLU = false, int PRO = PRO_NONE>
 __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   static_assert(!GEGLU || (CB == 4 && TPR == 1 && !RES && !RA), "GEGLU: 2 h + 2 g column blocks per compute wave, one tile per round, bias only");
+  static_assert(PRO == PRO_NONE || !RES, "prologue flavours: no residual (their consumers have none)");
+  static_assert(PRO != PRO_AFF || (!RA && !GEGLU), "PRO_AFF: bias only");
   using Cfg = WsCfg<KS, CB, TPR>;
   constexpr int K = Cfg::K, CPR = Cfg::CPR, GC = Cfg::GC, TR = Cfg::TR, STAGE = Cfg::STAGE, RSTAGE = Cfg::RSTAGE, NR = Cfg::NR,
                 CS_LD = Cfg::CS_LD;
@@ -122,6 +150,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   char* ring = smem;
   float* cst = reinterpret_cast<float*>(smem + NR * RSTAGE);       // staging tile (round parity, tile u): index (r & 1) * TPR + u
   char* ost = smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE;          // GEGLU: 2 x 2 KiB of finished fp16 pieces, loader -> store waves
+  float2_t* lst = reinterpret_cast<float2_t*>(smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE + Cfg::OSTAGE);   // PRO_LNF: (a, b) of round r, tile u, row: ((r & 3) * TPR + u) * TR + row
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // workgroup -> (XCD, column group, row stream): the G groups of one row stream share an XCD (blockIdx % 8)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -129,7 +158,11 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   if (sl >= p.spx) return;
   const int stream = xcd * p.spx + sl;
   const int ntiles = (p.M + TR - 1) / TR;
-  const int my_tiles = stream < ntiles ? (ntiles - stream + p.streams - 1) / p.streams : 0;   // tiles stream, stream+S, ...
+  // local tile t of this stream is tile tile0 + t * tstep: interleaved (stream, stream + S, ...), or one contiguous block per stream (PRO_AFF)
+  const int tps = (ntiles + p.streams - 1) / p.streams;
+  const int tile0 = PRO == PRO_AFF ? stream * tps : stream;
+  const int tstep = PRO == PRO_AFF ? 1 : p.streams;
+  const int my_tiles = PRO == PRO_AFF ? max(0, min(tps, ntiles - tile0)) : (stream < ntiles ? (ntiles - stream + p.streams - 1) / p.streams : 0);
   if (my_tiles == 0) return;
   const int rounds = (my_tiles + TPR - 1) / TPR;                  // barriers b_0 .. b_rounds
   const int n0 = grp * GC;
@@ -148,10 +181,12 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       gp.row = id / (GC / 16);
       const int oc = (id % (GC / 16)) * 8;
       gp.hcol = 64 * (oc >> 5) + (oc & 31);
-      const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol + 32) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (PRO != PRO_LNF) {
+        const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol + 32) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gp.bh[j] = (float)b0[j], gp.bg[j] = (float)b1[j];
+        for (int j = 0; j < 8; ++j) gp.bh[j] = (float)b0[j], gp.bg[j] = (float)b1[j];
+      }
     }
   }
 
@@ -167,11 +202,22 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     }
     const int row = lane & 15, kq = lane >> 4;
     const int rbase = row * CPR, sw = ws_swz<CPR>(row);
+    // PRO_LNF + GEGLU: s[n], c[n] of this lane's 4 * CB staging columns (the memory waves are bound by the GELU: the fold is applied here)
+    floatx4 lsv[GEGLU && PRO == PRO_LNF ? CB : 1], lcv[GEGLU && PRO == PRO_LNF ? CB : 1];
+    if constexpr (GEGLU && PRO == PRO_LNF) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        lsv[cb] = *reinterpret_cast<const floatx4*>(p.lnf + n0 + wave * 16 * CB + cb * 16 + 4 * kq);
+        lcv[cb] = *reinterpret_cast<const floatx4*>(p.lnf + p.N + n0 + wave * 16 * CB + cb * 16 + 4 * kq);
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): weights are in registers before the loop
     constexpr int PD = Cfg::PD;
     constexpr int SWB = CPR == 40 ? 3 : 4, P = (1 << SWB) / 4;
-    auto compute_tile = [&](const char* st, int buf) {
+    auto compute_tile = [&](const char* st, int buf, int lslot) {
       floatx4 acc[CB];
+      float2_t ab = {1.f, 0.f};
+      if constexpr (GEGLU && PRO == PRO_LNF) ab = lst[lslot * TR + row];      // (rstd, -mu rstd) of this lane's row, left by the loader waves
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
       // slot (4ks + kq) ^ sw: the swizzle only touches the low SWB bits, so there are P = 2^SWB / 4 distinct per-lane base
@@ -194,6 +240,10 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                       //     ahead of that step's CB MFMAs
       }
       // acc[cb][r] = C[m = row][n = wave*16CB + cb*16 + 4*kq + r]
+      if constexpr (GEGLU && PRO == PRO_LNF) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = ab.x * acc[cb] + (ab.y * lsv[cb] + lcv[cb]);
+      }
       float* cs = cst + buf * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
@@ -203,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       const char* st = ring + (r % NR) * RSTAGE;
 #pragma unroll
       for (int u = 0; u < TPR; ++u)
-        if (r * TPR + u < my_tiles) compute_tile(st + u * STAGE, (r & 1) * TPR + u);
+        if (r * TPR + u < my_tiles) compute_tile(st + u * STAGE, (r & 1) * TPR + u, (r & 3) * TPR + u);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging stores WRITTEN before the hand-over barrier
     }
     __builtin_amdgcn_s_barrier();                   // b_rounds
@@ -212,13 +262,77 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     // ------------------------------------------------------------------------------------------------ loader waves
     const int lw = wave - 4;
     const half_t* sp[Cfg::PER];
-    const size_t astep = (size_t)p.streams * TR * p.lda;
+    const size_t astep = (size_t)tstep * TR * p.lda;
 #pragma unroll
     for (int i = 0; i < Cfg::PER; ++i) {
       const int pidx = (lw * Cfg::PER + i) * 64 + lane;
       const int r = pidx / CPR, c = pidx % CPR;
-      sp[i] = p.A + (size_t)(stream * TR + r) * p.lda + ((c ^ ws_swz<CPR>(r)) << 3);
+      sp[i] = p.A + (size_t)(tile0 * TR + r) * p.lda + ((c ^ ws_swz<CPR>(r)) << 3);
     }
+    // Prologues.  Loader wave lw DMA'd rows 8 lw .. 8 lw + 7 of every tile itself (PER * 64 slots = 8 rows), so its own counted vmcnt
+    // wait is all it needs before touching them.  Lane (prow, psub): row prow, 16-byte chunks 8 j + psub, j < PJ (the swizzle only
+    // permutes chunks inside a group of 8 / 16, so chunk c of the row sits in LDS slot c ^ swz(row)).
+    static_assert(Cfg::PER * 64 == 8 * CPR, "a loader wave owns whole rows");
+    constexpr int PJ = CPR / 8;
+    const int prow = lw * 8 + (lane >> 3), psub = lane & 7;
+    const int pswz = ws_swz<CPR>(prow);
+    auto ln_stats = [&](const char* st, int lslot) {            // exact two-pass (mu, rstd) of the landed row -> (a, b) = (rstd, -mu rstd)
+      float v[PJ][8];
+#pragma unroll
+      for (int j = 0; j < PJ; ++j) {
+        const half8_t h = *reinterpret_cast<const half8_t*>(st + (prow * CPR + ((8 * j + psub) ^ pswz)) * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = (float)h[e];
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < PJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[j][e];
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      const float mu = sum * (1.0f / K);
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < PJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[j][e] - mu;
+          sq += d * d;
+        }
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      sq += __shfl_xor(sq, 4, 64);
+      const float a = rsqrtf(sq * (1.0f / K) + p.eps);
+      if (psub == 0) lst[lslot * TR + prow] = float2_t{a, -mu * a};
+    };
+    float asc[PRO == PRO_AFF ? PJ : 1][8], asf[PRO == PRO_AFF ? PJ : 1][8];
+    int cur_img = -1;
+    auto load_table = [&](int img) {                            // scale / shift of this lane's columns for image `img`; drains vmcnt
+      const float* t = p.aff + (size_t)img * 2 * K;
+#pragma unroll
+      for (int j = 0; j < (PRO == PRO_AFF ? PJ : 1); ++j) {
+        const floatx4 s0 = *reinterpret_cast<const floatx4*>(t + (8 * j + psub) * 8), s1 = *reinterpret_cast<const floatx4*>(t + (8 * j + psub) * 8 + 4);
+        const floatx4 f0 = *reinterpret_cast<const floatx4*>(t + K + (8 * j + psub) * 8), f1 = *reinterpret_cast<const floatx4*>(t + K + (8 * j + psub) * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asc[j][e] = s0[e], asc[j][e + 4] = s1[e], asf[j][e] = f0[e], asf[j][e + 4] = f1[e];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): everything landed (the DMAs in flight too); the counted waits
+      cur_img = img;                                            // below stay valid -- fewer operations are outstanding than they assume
+    };
+    auto aff_apply = [&](char* st) {                            // x * scale + shift, one rounding: gn_apply_kernel's arithmetic
+#pragma unroll
+      for (int j = 0; j < (PRO == PRO_AFF ? PJ : 1); ++j) {
+        char* a = st + (prow * CPR + ((8 * j + psub) ^ pswz)) * 16;
+        const half8_t h = *reinterpret_cast<const half8_t*>(a);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)h[e] * asc[j][e] + asf[j][e]);
+        *reinterpret_cast<half8_t*>(a) = o;
+      }
+    };
+    if constexpr (PRO == PRO_AFF) load_table((tile0 * TR) / p.rows_per_image);      // before the first DMA is issued
     auto issue_round = [&](int q) {                 // called with q = 0, 1, 2, ... in order; tiles are issued in order too
       char* st = ring + (q % NR) * RSTAGE;
 #pragma unroll
@@ -241,11 +355,27 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       // (TPR tiles, TPR*PER pieces each) as long as none of them is the last one -- otherwise simply drain.
       if (r + NR - 2 < rounds - 1) wait_vmcnt<(NR - 2) * TPR * Cfg::PER>();
       else wait_vmcnt<0>();
+      if constexpr (PRO != PRO_NONE) {              // round r has landed (this wave's rows): normalise / take the statistics before the hand-over
+        char* st = ring + (r % NR) * RSTAGE;
+#pragma unroll
+        for (int u = 0; u < TPR; ++u) {
+          const int t = r * TPR + u;
+          if (t < my_tiles) {
+            if constexpr (PRO == PRO_LNF) ln_stats(st + u * STAGE, (r & 3) * TPR + u);
+            if constexpr (PRO == PRO_AFF) {
+              const int img = ((tile0 + t * tstep) * TR) / p.rows_per_image;
+              if (img != cur_img) load_table(img);
+              aff_apply(st + u * STAGE);
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();                 // also: the compute waves are done with round r-1 -> its stage is free
       if (r + NR - 1 < rounds) issue_round(r + NR - 1);   // into stage (r - 1) % NR
       if constexpr (GEGLU) {
         if (r >= 1) {                               // this wave's piece of tile r-1 -> LDS (shipped by a store wave after b_{r+1})
-          const half8_t o = ws_geglu_piece(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          const half8_t o = ws_geglu_piece<PRO != PRO_LNF>(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
           *reinterpret_cast<half8_t*>(ost + ((r - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -253,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     }
     __builtin_amdgcn_s_barrier();                   // b_rounds
     if constexpr (GEGLU) {
-      const half8_t o = ws_geglu_piece(cst + ((rounds - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+      const half8_t o = ws_geglu_piece<PRO != PRO_LNF>(cst + ((rounds - 1) & 1) * (TR * CS_LD), CS_LD, gp);
       *reinterpret_cast<half8_t*>(ost + ((rounds - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // b_{rounds + 1}
@@ -264,9 +394,9 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       constexpr int OC = GC / 2;
       const int sw2 = wave - 6;                                          // 0 / 1: ships the pieces of loader wave sw2 as well
       const int id_own = (wave - 4) * 64 + lane, id_ld = sw2 * 64 + lane;
-      const size_t cstep = (size_t)p.streams * TR * p.ldc;
-      half_t* cp_own = p.C + (size_t)(stream * TR + id_own / (OC / 8)) * p.ldc + grp * OC + (id_own % (OC / 8)) * 8;
-      half_t* cp_ld = p.C + (size_t)(stream * TR + id_ld / (OC / 8)) * p.ldc + grp * OC + (id_ld % (OC / 8)) * 8;
+      const size_t cstep = (size_t)tstep * TR * p.ldc;
+      half_t* cp_own = p.C + (size_t)(tile0 * TR + id_own / (OC / 8)) * p.ldc + grp * OC + (id_own % (OC / 8)) * 8;
+      half_t* cp_ld = p.C + (size_t)(tile0 * TR + id_ld / (OC / 8)) * p.ldc + grp * OC + (id_ld % (OC / 8)) * 8;
       for (int r = 0; r <= rounds + 1; ++r) {
         __builtin_amdgcn_s_barrier();                                   // b_r
         if (r >= 2) {                                                   // loader pieces of tile r-2, parked in LDS during round r-1
@@ -274,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           cp_ld += cstep;
         }
         if (r >= 1 && r <= rounds) {                                    // own piece of tile r-1
-          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece<PRO != PRO_LNF>(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
           cp_own += cstep;
         }
       }
@@ -289,7 +419,8 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       float biasf[SPL][8];
       half_t* cp[SPL];
       const half_t* rp[SPL];
-      const size_t cstep = (size_t)p.streams * TR * p.ldc, rstep = (size_t)p.streams * TR * p.ldr;
+      const size_t cstep = (size_t)tstep * TR * p.ldc, rstep = (size_t)tstep * TR * p.ldr;
+      float lsf[PRO == PRO_LNF ? SPL : 1][8], lcf[PRO == PRO_LNF ? SPL : 1][8];      // PRO_LNF: s[n], c[n] of this lane's columns
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
         const int id = i * 128 + sid;
@@ -298,8 +429,14 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         const half8_t bv = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pcol[i]) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) biasf[i][j] = (float)bv[j];
-        cp[i] = p.C + (size_t)(stream * TR + prow[i]) * p.ldc + n0 + pcol[i];
-        rp[i] = RES ? p.residual + (size_t)(stream * TR + prow[i]) * p.ldr + n0 + pcol[i] : nullptr;
+        cp[i] = p.C + (size_t)(tile0 * TR + prow[i]) * p.ldc + n0 + pcol[i];
+        rp[i] = RES ? p.residual + (size_t)(tile0 * TR + prow[i]) * p.ldr + n0 + pcol[i] : nullptr;
+        if constexpr (PRO == PRO_LNF) {
+          const floatx4 s0 = *reinterpret_cast<const floatx4*>(p.lnf + n0 + pcol[i]), s1 = *reinterpret_cast<const floatx4*>(p.lnf + n0 + pcol[i] + 4);
+          const floatx4 c0 = *reinterpret_cast<const floatx4*>(p.lnf + p.N + n0 + pcol[i]), c1 = *reinterpret_cast<const floatx4*>(p.lnf + p.N + n0 + pcol[i] + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lsf[i][j] = s0[j], lsf[i][j + 4] = s1[j], lcf[i][j] = c0[j], lcf[i][j + 4] = c1[j];
+        }
       }
       constexpr int RD = RA ? 2 : Cfg::RES_DEPTH;     // residual tiles in flight per store wave (fewer when the row-broadcast term
                                                       // also lives in registers: 256 VGPRs per wave)
@@ -319,8 +456,8 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       };
       int cur_group = -1;
       float raf[RA ? SPL : 1][8];
-      auto store_tile = [&](int tile, int buf, const half8_t (&rs)[SPL]) {
-        const int m0 = (stream + tile * p.streams) * TR;
+      auto store_tile = [&](int tile, int buf, int lslot, const half8_t (&rs)[SPL]) {
+        const int m0 = (tile0 + tile * tstep) * TR;
         const float* cs = cst + buf * (TR * CS_LD);
         if constexpr (RA) {
           // row-broadcast term: one table row per `rows_per_group` output rows (a frame); reloaded when the tile enters a new
@@ -339,16 +476,23 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         }
         // all LDS reads first (one latency per tile, not one per piece), then the arithmetic
         floatx4 ca[SPL], cb2[SPL];
+        float2_t ab[PRO == PRO_LNF ? SPL : 1];
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
           ca[i] = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i]);
           cb2[i] = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i] + 4);
+          if constexpr (PRO == PRO_LNF) ab[i] = lst[lslot * TR + prow[i]];
         }
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
           float v[8] = {ca[i][0], ca[i][1], ca[i][2], ca[i][3], cb2[i][0], cb2[i][1], cb2[i][2], cb2[i][3]};
+          if constexpr (PRO == PRO_LNF) {           // LN(x) . W^T + bias = rstd (x . W'^T - mu s) + c
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += biasf[i][j];
+            for (int j = 0; j < 8; ++j) v[j] = ab[i].x * v[j] + (ab[i].y * lsf[i][j] + lcf[i][j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += biasf[i][j];
+          }
           if constexpr (RA) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += raf[i][j];
@@ -389,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
                 const int tile = (r - 1) * TPR + u;
                 const int slot_ = ((j + UNR - 1) % UNR) * TPR + u;    // == tile % RD, a compile-time value after unrolling
                 if (tile < my_tiles) {
-                  store_tile(tile, ((r - 1) & 1) * TPR + u, res[RES ? slot_ : 0]);
+                  store_tile(tile, ((r - 1) & 1) * TPR + u, ((r - 1) & 3) * TPR + u, res[RES ? slot_ : 0]);
                   if constexpr (RES) {
                     if (tile + RD < my_tiles) fetch_res(res[slot_]);
                   }

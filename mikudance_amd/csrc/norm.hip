@@ -288,6 +288,50 @@ extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const v
   return MD_OK;
 }
 
+// GroupNorm as a TABLE: the statistics sweep above, then scale[b][c] = rstd * gamma[c], shift[b][c] = beta[c] - mean * scale (exactly what
+// gn_apply_kernel derives per workgroup, same partial-sum order) written as fp32 [B][2][C].  The consumer -- md_gemm_affine_f16, the
+// proj_in of Transformer3DModel / the motion module's temporal transformer -- applies x * scale + shift to the rows it has just
+// streamed into LDS, so the normalised tensor never exists in HBM: 2 bytes per element (this sweep) instead of 6.
+__global__ void gn_table_kernel(const float* __restrict__ part, const float* __restrict__ pilot, const half_t* __restrict__ gamma,
+                                const half_t* __restrict__ beta, float* __restrict__ table, int HW, int C, int G, int nslab, float eps) {
+  const int b = blockIdx.x, cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    float a = 0.f, c2 = 0.f;
+    const float* pp = part + ((size_t)b * nslab * G + g) * 2;
+    for (int k = 0; k < nslab; ++k) {
+      a += pp[(size_t)k * G * 2];
+      c2 += pp[(size_t)k * G * 2 + 1];
+    }
+    const float n = (float)HW * (float)cpg;
+    const float mu = a / n;                               // mean of x - k
+    const float var = fmaxf(c2 / n - mu * mu, 0.f);
+    const float mean = pilot[(size_t)b * G + g] + mu;
+    const float sc = rsqrtf(var + eps) * (float)gamma[c];
+    table[(size_t)b * 2 * C + c] = sc;
+    table[(size_t)b * 2 * C + C + c] = (float)beta[c] - mean * sc;
+  }
+}
+
+extern "C" int md_groupnorm_table_f16(const void* x, int ldx, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps, float* table,
+                                      void* workspace, size_t ws_bytes, void* stream) {
+  MD_CHECK_ARG(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0, "md_groupnorm_table: need C %% 8 == 0, G <= 64, C %% G == 0 (C=%d G=%d)", C, G);
+  MD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "md_groupnorm_table: ldx=%d must be a multiple of 8 and >= C=%d, x 16-byte aligned", ldx, C);
+  MD_CHECK_ARG(C / 8 <= 1024 && (reinterpret_cast<uintptr_t>(table) & 15) == 0, "md_groupnorm_table: C=%d too large or table not 16-byte aligned", C);
+  MD_CHECK_ARG(ws_bytes >= md_groupnorm_workspace_bytes(B, HW, C, G), "md_groupnorm_table: workspace too small");
+  const int cch = C / 8;
+  int R, slab, nslab;
+  gn_geometry(B, HW, C, R, slab, nslab);
+  const dim3 grid(nslab, B), block(cch * R);
+  const size_t sh = (size_t)2 * R * C * sizeof(float);
+  float* pilot = (float*)workspace + (size_t)B * nslab * G * 2;
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, pilot, HW, C, ldx, G, R, slab, nslab);
+  hipLaunchKernelGGL(gn_table_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (const float*)pilot, (const half_t*)gamma,
+                     (const half_t*)beta, table, HW, C, G, nslab, eps);
+  MD_CHECK_LAUNCH("md_groupnorm_table");
+  return MD_OK;
+}
+
 extern "C" int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps, int silu,
                                      void* workspace, size_t ws_bytes, void* stream) {
   return md_groupnorm_ld_nhwc_f16(x, C, y, gamma, beta, B, HW, C, G, eps, silu, workspace, ws_bytes, stream);

@@ -110,7 +110,72 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
     return out
 
 
+def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False):
+    """True when md_gemm_ln_f16 has a kernel for the problem (else: layernorm + gemm on the unfolded weights)."""
+    return bool(_lib.load().md_gemm_ln_plan(M, N, K, act, 2 if rowadd else 0))
+
+
+def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None):
+    """out[M, N] = epi(LayerNorm(a) @ w^T + bias) from the RAW rows of a, with (wf, sc) = packing.ln_fold(w, bias, gamma, beta)."""
+    lda = _rowmajor(a, "a")
+    _chk(wf, "wf"); _chk(sc, "sc", torch.float32); _chk(rowadd, "rowadd")
+    M, K = a.shape
+    N = wf.shape[0]
+    assert wf.shape[1] == K and wf.is_contiguous() and sc.shape == (2, N) and sc.is_contiguous(), (wf.shape, sc.shape, K)
+    if out is None:
+        out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), device=a.device, dtype=F16)
+    ldc = _rowmajor(out, "out")
+    ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
+    _lib.call("md_gemm_ln_f16", a.data_ptr(), lda, wf.data_ptr(), sc.data_ptr(), out.data_ptr(), ldc, M, N, K, float(eps), _p(rowadd), ldra,
+              rows_per_group, act, _st(),
+              meta=(f"gemm M={M} N={N} K={K}" + (" geglu" if act == ACT_GEGLU else "") + " ln", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
+    return out
+
+
 _gn_ws = {}
+
+
+def _gn_workspace(x, B, HW, C, groups):
+    need = _lib.load().md_groupnorm_workspace_bytes(B, HW, C, groups)
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((max(need, 1 << 20) + 3) // 4, device=x.device, dtype=torch.float32)
+        _gn_ws[key] = ws
+    return ws
+
+
+def gemm_affine_plan(M, N, K, rows_per_image):
+    return bool(_lib.load().md_gemm_affine_plan(M, N, K, rows_per_image))
+
+
+def groupnorm_table(x, gamma, beta, groups, eps):
+    """Statistics sweep of GroupNorm only: fp32 (B, 2, C) = [rstd * gamma, beta - mean * rstd * gamma] for gemm_affine."""
+    _chk(gamma, "gamma"); _chk(beta, "beta")
+    ldx = _pixel_pitch(x, "x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    ws = _gn_workspace(x, B, HW, C, groups)
+    table = torch.empty((B, 2, C), device=x.device, dtype=torch.float32)
+    _lib.call("md_groupnorm_table_f16", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), B, HW, C, groups, float(eps), table.data_ptr(),
+              ws.data_ptr(), ws.numel() * 4, _st(), meta=(f"groupnorm B={B} HW={HW} C={C} stats", 0.0, 2.0 * B * HW * C))
+    return table
+
+
+def gemm_affine(x, table, w, bias=None, out=None):
+    """out[B*HW, N] = fp16(x * scale[image] + shift[image]) @ w^T + bias; x (B, HW, C) / (B, H, W, C) NHWC (a channel slice is fine)."""
+    lda = _pixel_pitch(x, "x")
+    _chk(w, "w"); _chk(bias, "bias"); _chk(table, "table", torch.float32)
+    B, K = x.shape[0], x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous() and table.shape == (B, 2, K) and table.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=F16)
+    ldc = _rowmajor(out, "out")
+    _lib.call("md_gemm_affine_f16", x.data_ptr(), lda, table.data_ptr(), M // B, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias), _st(),
+              meta=(f"gemm M={M} N={N} K={K} gn", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
+    return out
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu=False, out=None):
@@ -119,12 +184,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, out=None):
     ldx = _pixel_pitch(x, "x")
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
-    need = _lib.load().md_groupnorm_workspace_bytes(B, HW, C, groups)
-    key = (x.device, torch.cuda.current_stream().cuda_stream)
-    ws = _gn_ws.get(key)
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty((max(need, 1 << 20) + 3) // 4, device=x.device, dtype=torch.float32)
-        _gn_ws[key] = ws
+    ws = _gn_workspace(x, B, HW, C, groups)
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=F16)
     assert out.is_contiguous() and out.shape == x.shape

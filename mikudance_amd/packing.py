@@ -42,5 +42,23 @@ def geglu_weight(w, b, device):
     return wp.detach().to(device=device, dtype=F16).contiguous(), bp.detach().to(device=device, dtype=F16).contiguous()
 
 
+def ln_fold(w, bias, gamma, beta):
+    """LayerNorm(gamma, beta) folded into the Linear (w [N, K], bias [N] or None) that consumes it, for md_gemm_ln_f16:
+        LN(x) @ w.T + bias = rstd * (x @ wf.T - mu * s) + c,   wf = fp16(gamma * w),  s = wf.sum(1),  c = w @ beta + bias.
+    w / bias are the kernel-layout fp16 tensors (any row order: the GEGLU interleave commutes with the fold); gamma / beta are
+    taken at fp16 precision like every other parameter of the fp16 run.  s is summed from the ROUNDED wf so that
+    x @ wf.T - mu * s == (x - mu) @ wf.T exactly.  Returns (wf fp16 [N, K], sc fp32 [2, N] = [s, c])."""
+    dev = w.device
+    w32 = w.detach().to(F16).float()
+    g = gamma.detach().to(device=dev, dtype=F16).float()
+    b = beta.detach().to(device=dev, dtype=F16).double()
+    wf = (w32 * g[None, :]).to(F16).contiguous()
+    s = wf.double().sum(1)
+    c = w32.double() @ b
+    if bias is not None:
+        c = c + bias.detach().to(device=dev, dtype=F16).double()
+    return wf, torch.stack([s, c]).float().contiguous()
+
+
 def vec(t, device):
     return t.detach().to(device=device, dtype=F16).contiguous()

@@ -127,6 +127,67 @@ def layernorm(x, gamma, beta, eps=1e-5, add=None, add_mode=0, add_row_begin=0, r
     return y, y2
 
 
+# The fused-normalisation entry points (md_gemm_ln_f16, md_groupnorm_table_f16 + md_gemm_affine_f16).  The real plans only say yes on
+# the long token matrices of the 96 x 96 / 48 x 48 levels; FUSED = True makes the emulation say yes everywhere, so that the host-side
+# folding (packing.ln_fold, the GEGLU row order of s / c, the row term, the table layout) is executed at CPU-test sizes too.
+FUSED = False
+
+
+def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False):
+    return FUSED and not (act == ACT_GEGLU and rowadd)
+
+
+def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None):
+    assert a.dim() == 2 and a.stride(1) == 1 and a.dtype == F16 and wf.dtype == F16 and sc.dtype == torch.float32 and sc.shape == (2, wf.shape[0])
+    M, K = a.shape
+    N = wf.shape[0]
+    x = a.float()
+    mu = x.mean(1, keepdim=True)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)
+    acc = rstd * (x @ wf.float().t() - mu * sc[0]) + sc[1]            # the kernel's arithmetic: raw rows, folded weights
+    if act == ACT_GEGLU:
+        q = acc.view(M, N // 64, 2, 32)
+        acc = (q[:, :, 0] * F.gelu(q[:, :, 1])).reshape(M, N // 2)
+    if rowadd is not None:
+        acc = acc + rowadd.float()[torch.arange(M) // rows_per_group]
+    CALLS.append(("gemm_ln", (M, N, K, act)))
+    if out is None:
+        return acc.to(F16)
+    out.copy_(acc.to(F16))
+    return out
+
+
+def gemm_affine_plan(M, N, K, rows_per_image):
+    return FUSED
+
+
+def groupnorm_table(x, gamma, beta, groups, eps):
+    B, C = x.shape[0], x.shape[-1]
+    _pitch(x)
+    xi = x.float().reshape(B, -1, groups, C // groups)
+    mean = xi.mean((1, 3))
+    rstd = torch.rsqrt(xi.var((1, 3), unbiased=False) + eps)
+    sc = rstd.repeat_interleave(C // groups, 1) * gamma.float()
+    sf = beta.float() - mean.repeat_interleave(C // groups, 1) * sc
+    CALLS.append(("groupnorm_table", (tuple(x.shape), tuple(x.stride()))))
+    return torch.stack([sc, sf], 1).contiguous()
+
+
+def gemm_affine(x, table, w, bias=None, out=None):
+    B, K = x.shape[0], x.shape[-1]
+    _pitch(x)
+    assert table.shape == (B, 2, K) and table.dtype == torch.float32
+    n = (x.float().reshape(B, -1, K) * table[:, :1] + table[:, 1:]).to(F16)          # one rounding, like the in-LDS apply
+    acc = n.reshape(-1, K).float() @ w.float().t()
+    if bias is not None:
+        acc = acc + bias.float()
+    CALLS.append(("gemm_affine", (tuple(x.shape), tuple(x.stride()), w.shape[0])))
+    if out is None:
+        return acc.to(F16)
+    out.copy_(acc.to(F16))
+    return out
+
+
 def instnorm_spade(x, gamma_beta, eps=1e-5):
     B, C = x.shape[0], x.shape[-1]
     _pitch(x)
@@ -270,7 +331,7 @@ def require_gpu(t, who):
 def install(monkeypatch):
     """Replace the functions of mikudance_amd.ops by the emulations above for the duration of a test."""
     from mikudance_amd import ops
-    for name in ("gemm", "conv3x3", "groupnorm", "layernorm", "instnorm_spade", "attention", "softmax_rows_", "temporal_attention", "pack_nhwc",
+    for name in ("gemm", "gemm_ln_plan", "gemm_ln", "gemm_affine_plan", "groupnorm_table", "gemm_affine", "conv3x3", "groupnorm", "layernorm", "instnorm_spade", "attention", "softmax_rows_", "temporal_attention", "pack_nhwc",
                  "unpack_nhwc", "concat_channels", "window_accumulate", "cfg_ddim_step", "require_gpu"):
         monkeypatch.setattr(ops, name, globals()[name])
     del CALLS[:]

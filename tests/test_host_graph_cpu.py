@@ -56,6 +56,35 @@ def test_unet_pair_on_emulated_operators_matches_the_oracle(small, monkeypatch, 
     assert len(sliced_in) >= 20 and len(sliced_out) >= 40, (len(sliced_in), len(sliced_out))
 
 
+def test_unet_pair_with_the_fused_normalisations_matches_the_oracle(small, monkeypatch):
+    """The same pair with md_gemm_ln_f16 / md_gemm_affine_f16 taken EVERYWHERE (the real plans only say yes on the 96 x 96 / 48 x 48
+    levels' token counts): LayerNorm folded into to_q / q|k|v / ff.net.0 (packing.ln_fold: fp16(gamma W), s, c in the GEGLU row
+    order, the motion module's positional row term on top) and GroupNorm applied inside proj_in -- host side against the oracle."""
+    ref, den, ref_sd, den_sd = small
+    fake_ops.install(monkeypatch)
+    monkeypatch.setattr(fake_ops, "FUSED", True)
+    f, h, w = 3, 16, 16
+    lat, rl, emb = (t.half().float() for t in synth_inputs(f, h, w, ctx_len=5, ctx_dim=64, seed=5))
+    ref_out, banks, pred = _pair(ref, den, lat, rl, emb, f, h, w, 601)
+    for net in (ref, den):                                   # drop the folded weights again: other tests share these models
+        for m in net.modules():
+            if hasattr(m, "_pk"):
+                m._pk = None
+    with torch.no_grad():
+        g = rl.repeat(2, 1, 1, 1, 1).reshape(2 * f, 22, h, w)
+        ctx = emb.repeat((f, 1, 1))
+        want_banks, want_ref = O.reference_unet_forward(ref_sd, g, ctx)
+        want = O.denoising_unet_forward(den_sd, lat.repeat(2, 1, 1, 1, 1), torch.tensor(601), ctx[:2],
+                                        {k: v.half().float() for k, v in want_banks.items()}, cfg=True)
+    assert rel_l2(ref_out.float(), want_ref) < 2e-2 and cosine(ref_out.float(), want_ref) > 0.999
+    assert rel_l2(pred.float(), want) < 2e-2 and cosine(pred.float(), want) > 0.999, rel_l2(pred.float(), want)
+    names = [c[0] for c in fake_ops.CALLS]
+    # every LayerNorm but norm1 and every SiLU-free GroupNorm went through a fused entry point
+    n_blocks, n_motion = 16, 21
+    assert names.count("gemm_affine") == names.count("groupnorm_table") == 2 * n_blocks + n_motion
+    assert names.count("gemm_ln") == 2 * 2 * n_blocks + 3 * n_motion, names.count("gemm_ln")
+
+
 def test_skip_plan_matches_the_reference_channel_arithmetic(small):
     ref, den, _, _ = small
     for net in (ref, den):
