@@ -408,17 +408,65 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
             O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
             sweep2[n] = time.perf_counter() - t0
         best = min(sweep2, key=sweep2.get)
+        if os.environ.get("MD_CPU_WORKER_THREADS"):                      # experiments / tests: pin the per-worker thread count
+            best = int(os.environ["MD_CPU_WORKER_THREADS"])
+            torch.set_num_threads(best)
+            t0 = time.perf_counter()
+            O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
+            sweep2[best] = time.perf_counter() - t0
         dt2 = sweep2[best]
+        # (3) ALL usable cores: one ATen call does not scale past `best` intra-op threads at this size (the sweep above), independent
+        # frames do -- P = usable // best workers (Python threads of this process: every thread owns its own OpenMP team of `best`
+        # threads, the GIL is released inside ATen, the weights are shared), each running the SAME frame-step on its own frame.
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else avail
+        P = max(1, min(usable, avail) // best)
+        frames_in = [synth_inputs(f, h, w, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100 + i) for i in range(P)]
+
+        def worker(i):
+            torch.set_num_threads(best)                                  # per calling thread (OpenMP ICV)
+            with torch.no_grad():
+                O.denoise_loop(ref_sd, den_sd, *frames_in[i], 1, guidance_scale=args.guidance)
+
+        from concurrent.futures import ThreadPoolExecutor
+        dt3 = None
+        if P > 1:
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(P) as ex:
+                list(ex.map(worker, range(P)))
+            dt3 = time.perf_counter() - t0
         torch.set_num_threads(avail)
-    return {"value": f / (dt2 * args.ddim_steps), "unit": "frames/s", "cores": best, "physical_cores": physical, "kind": "port",
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            quota = open(path).read().strip()
+            break
+        except OSError:
+            pass
+    single = f / (dt2 * args.ddim_steps)
+    allcore = P * f / (dt3 * args.ddim_steps) if dt3 else single
+    eff = (dt2 / dt3) if dt3 else 1.0                                     # 1.0 = P workers finish in the time of one
+    use_all = allcore > single
+    top = max(sweep2)
+    verdict = "more intra-op threads are slower for ONE call" if sweep2[top] > 1.05 * sweep2[best] and top > best else "ONE call by thread count"
+    why = (f"{verdict} ({', '.join(f'{k}: {v:.1f} s' for k, v in sorted(sweep2.items()))}) while {P} "
+           f"independent workers x {best} threads finish in {dt3:.1f} s ({100 * eff:.0f} % of linear): the cores are usable (affinity {usable}, "
+           f"cgroup cpu.max '{quota}'), ATen's per-operator fork/join over 1-2 images does not spread further") if dt3 else \
+          f"single worker only (affinity {usable}, {avail} intra-op threads)"
+    return {"value": allcore if use_all else single, "unit": "frames/s", "cores": P * best if use_all else best, "physical_cores": physical,
+            "usable_cores": usable, "cgroup_cpu_max": quota, "kind": "port",
+            "single_process": {"frames_per_s": single, "threads": best, "s_per_frame_step": round(dt2, 2)},
+            "all_cores": {"workers": P, "threads_per_worker": best, "s_for_all_workers": round(dt3, 2) if dt3 else None,
+                          "frames_per_s": allcore, "parallel_efficiency": round(eff, 3)},
             "thread_sweep_s_per_step_at_size": {str(k): round(v, 2) for k, v in sorted(sweep2.items())},
             "config1_cores": threads, "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
             "config1_full_s": dt1, "config1_frames_per_s": 4.0 / dt1,
             "sample": f"after one warm-up pass each: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) on {threads} "
                       f"intra-op threads (best of the sweep) = {dt1:.1f} s; (2) 1 DDIM step of {f} frame at {args.size}x{args.size} (reference_unet + "
                       f"denoising_unet, CFG pair, fp32, full-width random-init weights, literal algorithm) timed on "
-                      f"{'/'.join(str(k) for k in sorted(sweep2))} threads, best = {best} threads = {dt2:.1f} s; value = {f} frame / "
-                      f"({args.ddim_steps} steps x {dt2:.1f} s): one frame-step extrapolated linearly over frames and steps"}
+                      f"{'/'.join(str(k) for k in sorted(sweep2))} threads, best = {best} threads = {dt2:.1f} s; (3) the same frame-step on "
+                      f"{P} independent frames at once, {best} threads each = {P * best} of {usable} usable cores; value = "
+                      f"{'(3)' if use_all else '(2)'}: frames / ({args.ddim_steps} steps x wall time), one frame-step extrapolated linearly over "
+                      f"frames and steps.  Why not one {avail}-thread call: {why}"}
 
 
 if __name__ == "__main__":

@@ -118,11 +118,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
   const int q0 = qblk * (32 * NW * QT) + wave * (32 * QT);
   const int lk8 = (p.Lk + 7) & ~7;
 
-#ifdef A2_HEADMAJOR   // layout experiment (timing / FETCH_SIZE only): Q and K as [batch][head][token][D], row pitch ldq = ldk = D
-  const half_t* Kb = p.K + ((size_t)kb * p.H + h) * p.kv_stride * p.ldk;
-#else
+  // (token-major Q / K: an 80-byte head slice straddles 128-byte lines, 2.8x the algorithmic fetch at d = 40.  A head-major build was
+  // measured in round 5 -- Q, K as [batch][head][token][D]: FETCH_SIZE 1.68 -> 0.87 GB per launch, time -1.1 % -- and not adopted:
+  // profiles/r05_ab_attention_head_major.log)
   const half_t* Kb = p.K + (size_t)kb * p.kv_stride * p.ldk + h * D;
-#endif
   const half_t* Vb = p.Vt + (size_t)h * D * p.ldvt + (size_t)kb * p.kv_stride;
 
   // constant rows of every V^T stage: ones in row D (softmax denominator), zeros in the rest of the padding
@@ -146,11 +145,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int qrow = min(q0 + u * 32 + ql, p.Lq - 1);
-#ifdef A2_HEADMAJOR
-    const half_t* Qp = p.Q + (((size_t)b * p.H + h) * p.Lq + qrow) * p.ldq;
-#else
     const half_t* Qp = p.Q + ((size_t)b * p.Lq + qrow) * p.ldq + h * D;
-#endif
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c = s * 16 + hi * 8;

@@ -88,14 +88,11 @@ __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
   p = p * p;                                       // |x| >~ 21: inf, r = 0, gelu = max(x, 0)
   const float2_t r = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
   const float2_t m = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
-#ifdef MD_GELU_INF_SAFE
   // |x| = inf: p^16 = inf, r = 0 and inf * 0 would be NaN: the product takes |x| clamped to a finite value, so gelu(+inf) = +inf and
-  // gelu(-inf) = 0 (the limits); NaN still travels through p and r
+  // gelu(-inf) = 0 (the limits); NaN still travels through p and r.  One v_min per value: +2.6 % on the K = 320 GEGLU kernel, +-1 % on the
+  // others (profiles/r05_ab_gelu_inf_guard.log).
   const float2_t axc = {fminf(ax.x, 3.0e38f), fminf(ax.y, 3.0e38f)};
   return m - axc * r;
-#else
-  return m - ax * r;
-#endif
 }
 // The same arithmetic on N independent pairs, stage by stage (pinned): a kernel with ONE wave per SIMD has nobody to cover the
 // 6 + 4 + 1 + 1 dependent packed operations of a single chain (the compiler emits them back to back with s_nop between them).
@@ -126,10 +123,8 @@ __device__ __forceinline__ void gelu_fast2_x(float2_t (&x)[N]) {
 #pragma unroll
   for (int c = 0; c < N; ++c) p[c] = float2_t{__builtin_amdgcn_rcpf(p[c].x), __builtin_amdgcn_rcpf(p[c].y)};
   __builtin_amdgcn_sched_barrier(0);
-#ifdef MD_GELU_INF_SAFE
 #pragma unroll
-  for (int c = 0; c < N; ++c) ax[c] = float2_t{fminf(ax[c].x, 3.0e38f), fminf(ax[c].y, 3.0e38f)};
-#endif
+  for (int c = 0; c < N; ++c) ax[c] = float2_t{fminf(ax[c].x, 3.0e38f), fminf(ax[c].y, 3.0e38f)};      // the |x| = inf guard (gelu_fast2)
 #pragma unroll
   for (int c = 0; c < N; ++c) x[c] = float2_t{fmaxf(x[c].x, 0.f), fmaxf(x[c].y, 0.f)} - ax[c] * p[c];
 }

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         const half8_t h = *reinterpret_cast<const half8_t*>(a);
         half8_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)h[e] * asc[j][e] + asf[j][e]);
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)__builtin_fmaf((float)h[e], asc[j][e], asf[j][e]);
         *reinterpret_cast<half8_t*>(a) = o;
       }
     };

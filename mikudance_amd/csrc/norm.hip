@@ -113,8 +113,8 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
     const int c = cc * 8 + e;
     const int g = c / cpg;
     sc[e] = rstd_s[g] * (float)gamma[c];
-    sf[e] = (float)beta[c] - mean_s[g] * sc[e];
-  }
+    sf[e] = __builtin_fmaf(-mean_s[g], sc[e], (float)beta[c]);        // explicit fma here, in gn_table_kernel and in the in-LDS apply of
+  }                                                                    // wsgemm_kernel<PRO_AFF>: the three must agree bit for bit
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
   const size_t base = (size_t)b * HW * C + cc * 8, xbase = (size_t)b * HW * ldx + cc * 8;
 #pragma unroll GN_UNROLL
@@ -123,7 +123,7 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float f = (float)v[e] * sc[e] + sf[e];
+      float f = __builtin_fmaf((float)v[e], sc[e], sf[e]);
       if (silu) f = silu_f(f);
       o[e] = (half_t)f;
     }
@@ -309,7 +309,7 @@ __global__ void gn_table_kernel(const float* __restrict__ part, const float* __r
     const float mean = pilot[(size_t)b * G + g] + mu;
     const float sc = rsqrtf(var + eps) * (float)gamma[c];
     table[(size_t)b * 2 * C + c] = sc;
-    table[(size_t)b * 2 * C + C + c] = (float)beta[c] - mean * sc;
+    table[(size_t)b * 2 * C + C + c] = __builtin_fmaf(-mean, sc, (float)beta[c]);
   }
 }
 

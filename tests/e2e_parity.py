@@ -32,6 +32,18 @@ from mikudance_amd.synth import synth_inputs  # noqa: E402
 FULL = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
 
 
+def _sliced(cls, lo, hi):
+    """A scheduler that keeps entries lo:hi of its N-step timestep list (N itself, and with it prev_t = t - 1000 // N, unchanged): lets a
+    test run ONE step of configs[4]'s 30-step schedule -- e.g. the second, t = 966 -> prev_t = 933, which is NOT the list's next entry
+    932 -- at full size."""
+    class Sliced(cls):
+        def set_timesteps(self, n, *a, **k):
+            r = super().set_timesteps(n, *a, **k)
+            self.timesteps = self.timesteps[lo:hi]
+            return self.timesteps if r is not None else None
+    return Sliced
+
+
 def _oracle_run(O, ref_sd, den_sd, inputs, steps, guidance, dtype, dev, **win):
     """oracle/cpu_ref.denoise_loop on `dev` in `dtype`; returns (final latents, [latents after each step]) as fp32 CPU tensors."""
     cast = lambda sd: {k: v.to(device=dev, dtype=dtype if v.is_floating_point() else v.dtype) for k, v in sd.items()}
@@ -51,8 +63,9 @@ def _oracle_run(O, ref_sd, den_sd, inputs, steps, guidance, dtype, dev, **win):
 
 
 def run(frames=4, steps=20, latent=96, guidance=3.5, models=None, with_fp16_oracle=True, seed=100, geom=FULL, ctx=(257, 768),
-        window=None, log=None):
-    """Returns the record described in the module docstring.  models = (ref, den, ref_sd, den_sd) or None (built here)."""
+        window=None, log=None, step_slice=None):
+    """Returns the record described in the module docstring.  models = (ref, den, ref_sd, den_sd) or None (built here).
+    step_slice = (lo, hi): only entries lo:hi of the `steps`-step schedule are executed (on both sides)."""
     from oracle import cpu_ref as O                                      # the checker
     dev = torch.device("cuda:0")
     say = log or (lambda *a: None)
@@ -62,23 +75,30 @@ def run(frames=4, steps=20, latent=96, guidance=3.5, models=None, with_fp16_orac
     win = dict(window or {})
     lat, rl, emb = synth_inputs(frames, latent, latent, ctx_len=ctx[0], ctx_dim=ctx[1], seed=seed)
     inputs = tuple(t.half().float() for t in (lat, rl, emb))            # every evaluation starts from the same fp16-representable values
-    pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+    sched_cls, osched = DDIMScheduler, None
+    n_run = steps
+    if step_slice is not None:
+        sched_cls = _sliced(DDIMScheduler, *step_slice)
+        osched = _sliced(O.DDIM, *step_slice)()
+        n_run = len(range(steps)[step_slice[0]:step_slice[1]])
+        win["scheduler"] = osched
+    pipe = MikuDanceVideoPipeline(None, None, ref, den, sched_cls(**SCHED_KWARGS))
     hip_curve = []
     t0 = time.time()
     hip = pipe.denoise(*(t.half().to(dev) for t in inputs), steps, guidance, callback=lambda i, t, x: hip_curve.append(x.float().cpu()),
-                       **win).float().cpu()
+                       **{k: v for k, v in win.items() if k != "scheduler"}).float().cpu()
     torch.cuda.synchronize()
     say(f"hip  {time.time() - t0:7.1f} s")
     t0 = time.time()
     o32, c32 = _oracle_run(O, ref_sd, den_sd, inputs, steps, guidance, torch.float32, dev, **win)
     say(f"o32  {time.time() - t0:7.1f} s")
-    rec = {"config": {"frames": frames, "ddim_steps": steps, "latent": [latent, latent], "guidance": guidance, "width": dict(geom)["block_out_channels"],
-                      "context_tokens": ctx[0], "windows": win or "single", "weights": "N(0, 1/fan_in) seeds 1234/4321", "seed_inputs": seed},
+    rec = {"config": {"frames": frames, "ddim_steps": steps, "steps_executed": list(step_slice) if step_slice else "all", "latent": [latent, latent], "guidance": guidance, "width": dict(geom)["block_out_channels"],
+                      "context_tokens": ctx[0], "windows": {k: v for k, v in win.items() if k != "scheduler"} or "single", "weights": "N(0, 1/fan_in) seeds 1234/4321", "seed_inputs": seed},
            "tolerance": {"rel_l2": 3e-2, "cosine": 0.999, "source": "SURVEY.md 8c"},
            "hip_vs_o32": {"rel_l2": rel_l2(hip, o32), "cosine": cosine(hip, o32),
                           "per_step_rel_l2": [rel_l2(a, b) for a, b in zip(hip_curve, c32)]},
            "final_latent_rms": float(o32.double().pow(2).mean().sqrt())}
-    assert len(hip_curve) == len(c32) == steps
+    assert len(hip_curve) == len(c32) == n_run
     if with_fp16_oracle:
         t0 = time.time()
         o16, c16 = _oracle_run(O, ref_sd, den_sd, inputs, steps, guidance, torch.float16, dev, **win)

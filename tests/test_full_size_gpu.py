@@ -51,3 +51,20 @@ def test_config5_size_one_step_finite_and_deterministic(full):
     assert torch.equal(a, b)
     assert float((a.float() - args[0].float()).abs().flatten(3).amax(-1).amin()) > 0          # every (channel, frame) moved
     assert torch.cuda.max_memory_allocated(dev) < 96 * 2 ** 30                # incl. whatever earlier tests of the session peaked at
+
+
+def test_config5_one_step_of_its_30_step_schedule_vs_fp32_restatement(full):
+    """BASELINE configs[4] against the ORACLE at its own geometry and schedule: one window of 30 frames at 128 x 128 latents (60-frame
+    UNet batches, Lq = Lk = 16384 at d = 40, the F = 30 temporal attention), full width, CFG 3.5, and the SECOND step of the 30-step DDIM
+    schedule -- t = 966, whose prev_t = t - 1000 // 30 = 933 is not the list's next entry 932 (SURVEY App. A: both formulas literally).
+    fp32 restatement evaluated through PyTorch-ROCm on the GPU (tests/e2e_parity.py); tolerance of SURVEY 8c.  The whole 30 steps x 3
+    windows x 48 frames are a builder-run record: profiles/r05_e2e_parity_cfg4_30steps.json."""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from e2e_parity import run
+    rec = run(frames=30, steps=30, latent=128, models=full, with_fp16_oracle=False, step_slice=(1, 2),
+              window=dict(context_frames=30, context_stride=1, context_overlap=8))
+    print("\nE2E_CFG4_STEP " + json.dumps(rec))
+    h = rec["hip_vs_o32"]
+    assert rec["config"]["steps_executed"] == [1, 2] and len(h["per_step_rel_l2"]) == 1
+    assert h["rel_l2"] <= 3e-2 and h["cosine"] >= 0.999, h
