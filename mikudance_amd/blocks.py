@@ -178,7 +178,7 @@ def _pack_ff(ff, dev, pk, prefix="ff"):
 # W-stationary streaming GEMM serves the consumer (K = 320 / 640 on >= 32768 tokens: the 96 x 96 and 48 x 48 levels), a LayerNorm is
 # folded into its Linear (md_gemm_ln_f16) and a SiLU-free GroupNorm is applied to the rows inside the GEMM (md_gemm_affine_f16);
 # everywhere else the literal pair of operators runs.  norm1 stays a kernel of its own: its output IS the bank / K-V operand.
-FUSE_NORMS = True
+FUSE_NORMS = __import__("os").environ.get("MD_FUSE_NORMS", "1") != "0"      # MD_FUSE_NORMS=0: A/B runs against the literal operator pairs
 
 
 def ln_linear(pk, h, norm, lin, bias=None, rowadd=None, rows_per_group=0, act=ops.ACT_NONE, eps=1e-5):
