@@ -1,6 +1,7 @@
 """smoke(): one tiny invocation of the hot path on cuda:0 (reduced-width UNets, 16x16 latents, 4 frames, 2 DDIM steps),
 checked against the CPU oracle.  The oracle is used here ONLY as the checker (see oracle/cpu_ref.py header)."""
 import json
+import math
 import os
 
 import torch
@@ -18,45 +19,67 @@ SCHED_KWARGS = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", 
                     prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
 
 
-def _cache_file(cls, geom, kw, seed, mode):
-    """Synthetic fp16 weights are a pure function of (class, geometry, seed, mode): tests and bench.py build the same 2.2 G
-    parameters in up to six processes per run (25-40 s of CPU randn each), so the fp16 copy is kept under the system temp
-    directory and mapped back by later builds.  MD_SYNTH_CACHE=0 switches it off; nothing but seeded random weights ever goes
-    through it (real checkpoints load through from_pretrained_2d / load_state_dict)."""
-    import hashlib
+def _cache_dir():
+    """Per-user cache directory for the seeded synthetic weights: MD_SYNTH_CACHE_DIR, else <tmp>/mdance_synth_cache_<uid>, created with
+    mode 0700 and used only when this user owns it and nobody else can write to it (a shared, predictable temp path is not a place to
+    load tensors from).  None: no cache."""
     import tempfile
+    d = os.environ.get("MD_SYNTH_CACHE_DIR") or os.path.join(tempfile.gettempdir(), f"mdance_synth_cache_{os.getuid() if hasattr(os, 'getuid') else 0}")
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+        if hasattr(os, "getuid") and (st.st_uid != os.getuid() or (st.st_mode & 0o022)):
+            return None
+    except OSError:
+        return None
+    return d
+
+
+def _cache_file(cls, geom, kw, seed, mode):
+    """Synthetic fp16 weights are a pure function of (class, geometry, seed, mode, the generator's source): tests and bench.py build
+    the same 2.2 G parameters in up to six processes per run (25-40 s of CPU randn each), so the fp16 copy is kept in the per-user cache
+    directory and mapped back by later builds.  The key carries a hash of mikudance_amd/synth.py, so a change to the generator can
+    never pair stale cached weights with freshly generated oracle weights.  MD_SYNTH_CACHE=0 switches it off; nothing but seeded random
+    weights ever goes through it (real checkpoints load through from_pretrained_2d / load_state_dict)."""
+    import hashlib
     if os.environ.get("MD_SYNTH_CACHE", "1") == "0":
         return None
-    key = hashlib.sha1(repr((cls.__name__, sorted(geom.items()), sorted((k, repr(v)) for k, v in kw.items()), seed, mode, 2)).encode()).hexdigest()[:16]
-    d = os.path.join(tempfile.gettempdir(), "mdance_synth_cache")
-    os.makedirs(d, exist_ok=True)
+    d = _cache_dir()
+    if d is None:
+        return None
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth.py"), "rb") as fh:
+        gen = hashlib.sha1(fh.read()).hexdigest()
+    key = hashlib.sha1(repr((cls.__name__, sorted(geom.items()), sorted((k, repr(v)) for k, v in kw.items()), seed, mode, gen)).encode()).hexdigest()[:16]
     return os.path.join(d, f"{cls.__name__}_{key}_f16.safetensors")
 
 
 def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device="cuda", dtype=torch.float16, keep_state_dicts=True):
     """Both UNets with seeded synthetic weights (no checkpoints exist offline).  Returns (ref, den, ref_sd, den_sd); the fp32
-    state dicts are dropped (None) unless keep_state_dicts -- they are only needed to feed the CPU oracle.  One model at a
-    time is materialised on the host (8 ranks x 2.2 G fp32 parameters would otherwise cost ~150 GB of host RAM)."""
+    state dicts are dropped (None) unless keep_state_dicts -- they are only needed to feed the CPU oracle.  Without them the weights
+    are synthesised ONE TENSOR AT A TIME straight into the target dtype (the module is built on the meta device and filled by
+    assignment), so a rank's host footprint is the fp16 model plus one tensor: 8 ranks building 2.2 G parameters side by side on a
+    cold cache need ~8 x 4.4 GB instead of 8 x 13 GB (tools/cold_start.py, profiles/r05_cold_start_8rank.json)."""
     from . import UNet2DConditionModel, UNet3DConditionModel
-    from .synth import synth_state_dict
+    from .synth import synth_state_dict, synth_tensors
     geom = dict(SMALL if geom is None else geom)
     out = []
     for cls, kw, seed in ((UNet2DConditionModel, {}, seed_ref), (UNet3DConditionModel, MM_KWARGS, seed_den)):
         cache = _cache_file(cls, geom, kw, seed, mode) if dtype == torch.float16 else None
+        with torch.device("meta"):
+            model = cls(sample_size=16, **geom, **kw)
         if cache is not None and not keep_state_dicts and os.path.exists(cache):
             from safetensors.torch import load_file
-            with torch.device("meta"):
-                model = cls(sample_size=16, **geom, **kw)
             model.load_state_dict(load_file(cache, device="cpu"), strict=True, assign=True)
             out.append((model.to(device=device), None))
             continue
-        with torch.device("meta"):
-            shapes = {k: tuple(v.shape) for k, v in cls(sample_size=16, **geom, **kw).state_dict().items()}
-        sd = synth_state_dict(shapes, seed=seed, mode=mode)
-        model = cls(sample_size=16, **geom, **kw)
-        model.load_state_dict(sd, strict=True)
-        model = model.to(dtype=dtype)
-        if cache is not None and not os.path.exists(cache) and sum(v.numel() for v in sd.values()) > 50_000_000 \
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        if keep_state_dicts:
+            sd = synth_state_dict(shapes, seed=seed, mode=mode)
+            model.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True, assign=True)
+        else:
+            sd = None
+            model.load_state_dict({k: v.to(dtype) for k, v in synth_tensors(shapes, seed=seed, mode=mode)}, strict=True, assign=True)
+        if cache is not None and not os.path.exists(cache) and sum(math.prod(s) for s in shapes.values()) > 50_000_000 \
                 and os.environ.get("LOCAL_RANK", "0") == "0":              # one writer per host
             from safetensors.torch import save_file
             tmp = f"{cache}.{os.getpid()}.tmp"
@@ -66,7 +89,7 @@ def build_models(geom=None, seed_den=1234, seed_ref=4321, mode="fan_in", device=
             except OSError:
                 pass                                                   # a full or read-only temp directory only costs the next build its time
         model = model.to(device=device)
-        out.append((model, sd if keep_state_dicts else None))
+        out.append((model, sd))
         del sd
     (ref, ref_sd), (den, den_sd) = out
     return ref, den, ref_sd, den_sd

@@ -28,30 +28,34 @@ def positional_encoding_table(d_model, max_len=32):
     return pe
 
 
-def synth_state_dict(shapes, seed=1234, mode="fan_in"):
-    """shapes: dict key -> shape.  mode 'fan_in': weights N(0, 1/fan_in) (O(1) activations: sensitive parity
-    tests); mode 'n002': N(0, 0.02^2) (SURVEY.md 8d bench weights).  Norm weights 1 + N(0, 0.02^2), biases
-    N(0, 0.02^2), pos_encoder.pe analytic."""
-    out = {}
+def synth_tensors(shapes, seed=1234, mode="fan_in"):
+    """Generator form of synth_state_dict: yields (key, fp32 tensor) one at a time (every tensor is a pure function of its key, the
+    seed and the mode), so a caller that casts / moves each tensor as it arrives never holds a second copy of the model."""
     for key in sorted(shapes):
         shape = tuple(shapes[key])
         if key.endswith("pos_encoder.pe"):
-            out[key] = positional_encoding_table(shape[2], shape[1])
+            yield key, positional_encoding_table(shape[2], shape[1])
             continue
         g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
         r = torch.randn(shape, generator=g, dtype=torch.float32)
         if _is_norm_weight(key):
-            out[key] = 1.0 + 0.02 * r
+            yield key, 1.0 + 0.02 * r
         elif key.endswith(".bias"):
-            out[key] = 0.02 * r
+            yield key, 0.02 * r
         elif mode == "fan_in":
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            out[key] = r / math.sqrt(max(fan_in, 1))
+            yield key, r / math.sqrt(max(fan_in, 1))
         else:
-            out[key] = 0.02 * r
-    return out
+            yield key, 0.02 * r
+
+
+def synth_state_dict(shapes, seed=1234, mode="fan_in"):
+    """shapes: dict key -> shape.  mode 'fan_in': weights N(0, 1/fan_in) (O(1) activations: sensitive parity
+    tests); mode 'n002': N(0, 0.02^2) (SURVEY.md 8d bench weights).  Norm weights 1 + N(0, 0.02^2), biases
+    N(0, 0.02^2), pos_encoder.pe analytic."""
+    return dict(synth_tensors(shapes, seed=seed, mode=mode))
 
 
 def synth_inputs(frames, h, w, ctx_len=257, ctx_dim=768, seed=100):

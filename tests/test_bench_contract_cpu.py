@@ -115,3 +115,21 @@ def test_two_rank_launch_protocol_under_gloo():
         assert d["value"] is None and "dry-run" in d["data"] and d["config"]["parallelism"] == "dp2"
         assert d["config"]["input_staging"] == ("scatter" if extra else "rank-local")
         assert d["clip_means"][0] != d["clip_means"][1]                  # two different clips (seeds 100, 101) came back in rank order
+
+
+def test_eight_rank_launch_protocol_under_gloo():
+    """The driver's N = 8 command line (python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...) on the CPU over gloo with
+    the kernels replaced by a stand-in: 8 ranks rendezvous, every rank stages its own clip, ONE gather, one JSON line from rank 0 with 8
+    different clips in rank order, every rank leaves through destroy_process_group()."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--small",
+           "--dry-run-cpu", "--size", "128", "--frames", "4", "--ddim-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["clips_gathered"] == 8 and d["config"]["parallelism"] == "dp8"
+    assert len(set(d["clip_means"])) == 8                               # eight different clips (seeds 100 .. 107) came back
