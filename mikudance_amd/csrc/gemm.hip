@@ -602,96 +602,117 @@ static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
   hipLaunchKernelGGL((wsgemm_kernel<10, 4, 1, false, false, true>), dim3(256), dim3(512), smem, stream, p);
 }
 
-// ---- prologue flavours of the streaming kernel (gemm_ws.h: PRO_LNF, PRO_AFF) ------------------------------------------------
-// Shapes: the same as the plain / GEGLU streaming flavours (K = 320 or 640, long M), no residual.  Returns 0 (no such kernel),
-// 1 plain K = 320, 2 plain K = 640, 3 GEGLU K = 320.
-static int ws_pro_shape(int M, int N, int K, int act, int lda, int ldc) {
-  if (M < 32768 || M % 16 || lda % 8 || ldc % 8) return 0;
-  if (act == ACT_GEGLU) return (K == 320 && N % 256 == 0 && N / 256 <= 16) ? 3 : 0;
-  if (act != ACT_NONE) return 0;
-  if (K == 320 && N % 320 == 0 && N / 320 <= 8) return 1;
-  if (K == 640 && N % 128 == 0 && N / 128 <= 16) return 2;
-  return 0;
-}
-
-template <int KS, int CB, int TPR, bool RA, bool GEGLU, int PRO>
-static void launch_ws_pro_variant(const WsParams& p, hipStream_t stream) {
-  using Cfg = WsCfg<KS, CB, TPR>;
-  md_ensure_dynamic_lds<wsgemm_kernel<KS, CB, TPR, false, RA, GEGLU, PRO>>(Cfg::SMEM);
-  hipLaunchKernelGGL((wsgemm_kernel<KS, CB, TPR, false, RA, GEGLU, PRO>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
-}
-
-template <int KS, int CB, int PRO>
-static void launch_ws_pro(WsParams& p, hipStream_t stream) {
-  constexpr int GC = 64 * CB;
-  p.groups = p.N / GC;
-  p.spx = 32 / p.groups;
-  p.streams = 8 * p.spx;
-  if constexpr (PRO == PRO_AFF) {
-    if (p.groups > 1) launch_ws_pro_variant<KS, CB, 2, false, false, PRO>(p, stream);
-    else launch_ws_pro_variant<KS, CB, 1, false, false, PRO>(p, stream);
-  } else {
-    if (p.groups > 1) {
-      if (p.rowadd) launch_ws_pro_variant<KS, CB, 2, true, false, PRO>(p, stream);
-      else launch_ws_pro_variant<KS, CB, 2, false, false, PRO>(p, stream);
-    } else {
-      if (p.rowadd) launch_ws_pro_variant<KS, CB, 1, true, false, PRO>(p, stream);
-      else launch_ws_pro_variant<KS, CB, 1, false, false, PRO>(p, stream);
-    }
-  }
-}
-
+// ---- fused-normalisation flavours of the streaming kernel (gemm_ws.h: PRO_LNF / PRO_LNS / PRO_AFF prologues, STATS epilogue) --------
+// K = 320 only (the 96 x 96 level), M >= 32768 rows in whole 16-row tiles, no residual on the consumers.  Measured and NOT built in: the
+// K = 640 forms (the loader waves' in-LDS work per 20-KiB tile doubles the tile time: profiles/r05_ab_fused_norms_first_build.log) and
+// GEGLU with in-kernel statistics (its memory waves are VALU bound by the GELU).
+static bool ws_fused_rows(int M, int lda, int ldc) { return M >= 32768 && M % 16 == 0 && lda % 8 == 0 && ldc % 8 == 0; }
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// epi: bit 1 = row-broadcast operand.  1 when md_gemm_ln_f16 has a kernel for the problem (dense operands assumed), else 0: the caller
-// then runs md_layernorm_f16 + md_gemm_f16 on the unfolded weights.
-extern "C" int md_gemm_ln_plan(int M, int N, int K, int act, int epi) {
-  const int sh = ws_pro_shape(M, N, K, act, K, act == ACT_GEGLU ? N / 2 : N);
-  if (sh == 3 && (epi & 2)) return 0;
-  return sh ? 1 : 0;
+template <int CB, int TPR, bool RES, bool RA, bool GEGLU, int PRO, bool STATS>
+static void launch_ws_fused(const WsParams& p, hipStream_t stream) {
+  using Cfg = WsCfg<10, CB, TPR>;
+  md_ensure_dynamic_lds<wsgemm_kernel<10, CB, TPR, RES, RA, GEGLU, PRO, STATS>>(Cfg::SMEM);
+  hipLaunchKernelGGL((wsgemm_kernel<10, CB, TPR, RES, RA, GEGLU, PRO, STATS>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
 }
 
-extern "C" int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, void* C, int ldc, int M, int N, int K, float eps,
-                              const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
-  const int sh = ws_pro_shape(M, N, K, act, lda, ldc);
-  MD_CHECK_ARG(sh != 0 && !(sh == 3 && rowadd), "md_gemm_ln: no fused LayerNorm kernel for M=%d N=%d K=%d act=%d (ask md_gemm_ln_plan first)", M, N, K, act);
-  MD_CHECK_ARG(al16(A) && al16(Wf) && al16(C) && al16(sc) && al16(rowadd) && (!rowadd || (ldra % 8 == 0 && rows_per_group > 0)),
-               "md_gemm_ln: operands must be 16-byte aligned (ldra %% 8 == 0, rows_per_group > 0 with rowadd)");
+static void ws_groups(WsParams& p, int gc) {
+  p.groups = p.N / gc;
+  p.spx = 32 / p.groups;
+  p.streams = 8 * p.spx;
+}
+
+// epi: bit 0 residual, bit 1 row-broadcast operand, bit 3 (8) row statistics supplied.  1 when md_gemm_ln_f16 has a kernel for the
+// problem (dense operands assumed), else 0: the caller then runs md_layernorm_f16 + md_gemm_f16 on the unfolded weights.
+extern "C" int md_gemm_ln_plan(int M, int N, int K, int act, int epi) {
+  if (K != 320 || !ws_fused_rows(M, K, 8) || (epi & 1)) return 0;
+  if (act == ACT_GEGLU) return (epi & 8) && !(epi & 2) && N % 256 == 0 && N / 256 <= 16;
+  return act == ACT_NONE && N % 320 == 0 && N / 320 <= 8;
+}
+
+extern "C" int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, const float* stats, void* C, int ldc, int M, int N, int K,
+                              float eps, const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
+  MD_CHECK_ARG(md_gemm_ln_plan(M, N, K, act, (rowadd ? 2 : 0) | (stats ? 8 : 0)) && ws_fused_rows(M, lda, ldc),
+               "md_gemm_ln: no fused LayerNorm kernel for M=%d N=%d K=%d act=%d rowadd=%d stats=%d (ask md_gemm_ln_plan first)", M, N, K, act,
+               rowadd != nullptr, stats != nullptr);
+  MD_CHECK_ARG(al16(A) && al16(Wf) && al16(C) && al16(sc) && al16(rowadd) && (!rowadd || (ldra % 8 == 0 && rows_per_group > 0)) &&
+                   (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
+               "md_gemm_ln: operands must be 16-byte aligned (stats 8-byte; ldra %% 8 == 0, rows_per_group > 0 with rowadd)");
   WsParams p = {};
   p.A = (const half_t*)A; p.W = (const half_t*)Wf; p.C = (half_t*)C; p.rowadd = (const half_t*)rowadd;
   p.lda = lda; p.ldc = ldc; p.ldra = ldra; p.M = M; p.N = N; p.rows_per_group = rowadd ? rows_per_group : 1;
-  p.lnf = sc; p.eps = eps;
+  p.lnf = sc; p.eps = eps; p.stats_in = stats;
   hipStream_t st = (hipStream_t)stream;
-  if (sh == 1) launch_ws_pro<10, 5, PRO_LNF>(p, st);
-  else if (sh == 2) launch_ws_pro<20, 2, PRO_LNF>(p, st);
-  else {
-    p.groups = N / 256; p.spx = 32 / p.groups; p.streams = 8 * p.spx;
-    launch_ws_pro_variant<10, 4, 1, false, true, PRO_LNF>(p, st);
+  if (act == ACT_GEGLU) {
+    ws_groups(p, 256);
+    launch_ws_fused<4, 1, false, false, true, PRO_LNS, false>(p, st);
+  } else {
+    ws_groups(p, 320);
+    const bool multi = p.groups > 1, ra = rowadd != nullptr;
+#define MD_LN_CASE(TPR_, RA_)                                                           \
+  if (stats) launch_ws_fused<5, TPR_, false, RA_, false, PRO_LNS, false>(p, st);        \
+  else launch_ws_fused<5, TPR_, false, RA_, false, PRO_LNF, false>(p, st)
+    if (multi && ra) { MD_LN_CASE(2, true); }
+    else if (multi) { MD_LN_CASE(2, false); }
+    else if (ra) { MD_LN_CASE(1, true); }
+    else { MD_LN_CASE(1, false); }
+#undef MD_LN_CASE
   }
   MD_CHECK_LAUNCH("md_gemm_ln");
   return MD_OK;
 }
 
+// epi: bit 0 residual, bit 1 row-broadcast operand.  1 when md_gemm_stats_f16 has a kernel: N = K = 320 (one column group: the store
+// waves hold whole output rows).
+extern "C" int md_gemm_stats_plan(int M, int N, int K, int epi) { return K == 320 && N == 320 && ws_fused_rows(M, K, N); }
+
+extern "C" int md_gemm_stats_f16(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, const void* bias, const void* residual,
+                                 int ldr, const void* rowadd, int ldra, int rows_per_group, float eps, float* stats, void* stream) {
+  MD_CHECK_ARG(md_gemm_stats_plan(M, N, K, 0) && ws_fused_rows(M, lda, ldc) && stats != nullptr,
+               "md_gemm_stats: no kernel that emits row statistics for M=%d N=%d K=%d (ask md_gemm_stats_plan first)", M, N, K);
+  MD_CHECK_ARG(al16(A) && al16(W) && al16(C) && al16(bias) && al16(residual) && al16(rowadd) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0 &&
+                   (!residual || ldr % 8 == 0) && (!rowadd || (ldra % 8 == 0 && rows_per_group > 0)),
+               "md_gemm_stats: operands must be 16-byte aligned (stats 8-byte), pitches multiples of 8");
+  MD_CHECK_ARG(!residual || residual != C || ldr == ldc, "md_gemm_stats: in-place residual needs ldr == ldc");
+  WsParams p = {};
+  p.A = (const half_t*)A; p.W = (const half_t*)W; p.C = (half_t*)C; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
+  p.rowadd = (const half_t*)rowadd;
+  p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldra = ldra; p.M = M; p.N = N; p.rows_per_group = rowadd ? rows_per_group : 1;
+  p.stats_out = stats; p.eps_out = eps;
+  ws_groups(p, 320);
+  hipStream_t st = (hipStream_t)stream;
+  if (residual && rowadd) launch_ws_fused<5, 1, true, true, false, PRO_NONE, true>(p, st);
+  else if (residual) launch_ws_fused<5, 1, true, false, false, PRO_NONE, true>(p, st);
+  else if (rowadd) launch_ws_fused<5, 1, false, true, false, PRO_NONE, true>(p, st);
+  else launch_ws_fused<5, 1, false, false, false, PRO_NONE, true>(p, st);
+  MD_CHECK_LAUNCH("md_gemm_stats");
+  return MD_OK;
+}
+
+// bit 0: md_gemm_affine_f16 has a kernel for the problem; bit 1: it can also emit the row statistics of its output (N = 320)
 extern "C" int md_gemm_affine_plan(int M, int N, int K, int rows_per_image) {
-  if (rows_per_image <= 0 || rows_per_image % 16 || M % rows_per_image) return 0;
-  const int sh = ws_pro_shape(M, N, K, ACT_NONE, K, N);
-  return sh == 1 || sh == 2;
+  if (rows_per_image <= 0 || rows_per_image % 16 || M % rows_per_image || K != 320 || N % 320 || N / 320 > 8 || !ws_fused_rows(M, K, N)) return 0;
+  return N == 320 ? 3 : 1;
 }
 
 extern "C" int md_gemm_affine_f16(const void* A, int lda, const float* table, int rows_per_image, const void* W, void* C, int ldc, int M, int N,
-                                  int K, const void* bias, void* stream) {
-  const int sh = ws_pro_shape(M, N, K, ACT_NONE, lda, ldc);
-  MD_CHECK_ARG((sh == 1 || sh == 2) && rows_per_image > 0 && rows_per_image % 16 == 0 && M % rows_per_image == 0,
-               "md_gemm_affine: no fused kernel for M=%d N=%d K=%d rows_per_image=%d (ask md_gemm_affine_plan first)", M, N, K, rows_per_image);
-  MD_CHECK_ARG(al16(A) && al16(W) && al16(C) && al16(table) && al16(bias), "md_gemm_affine: operands must be 16-byte aligned");
+                                  int K, const void* bias, float eps, float* stats, void* stream) {
+  const int plan = md_gemm_affine_plan(M, N, K, rows_per_image);
+  MD_CHECK_ARG(plan && ws_fused_rows(M, lda, ldc) && (!stats || (plan & 2)),
+               "md_gemm_affine: no fused kernel for M=%d N=%d K=%d rows_per_image=%d stats=%d (ask md_gemm_affine_plan first)", M, N, K, rows_per_image,
+               stats != nullptr);
+  MD_CHECK_ARG(al16(A) && al16(W) && al16(C) && al16(table) && al16(bias) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
+               "md_gemm_affine: operands must be 16-byte aligned (stats 8-byte)");
   MD_CHECK_ARG(A != C, "md_gemm_affine: in place is not supported");
   WsParams p = {};
   p.A = (const half_t*)A; p.W = (const half_t*)W; p.C = (half_t*)C; p.bias = (const half_t*)bias;
   p.lda = lda; p.ldc = ldc; p.M = M; p.N = N; p.rows_per_group = 1;
-  p.aff = table; p.rows_per_image = rows_per_image;
+  p.aff = table; p.rows_per_image = rows_per_image; p.stats_out = stats; p.eps_out = eps;
+  ws_groups(p, 320);
   hipStream_t st = (hipStream_t)stream;
-  if (sh == 1) launch_ws_pro<10, 5, PRO_AFF>(p, st);
-  else launch_ws_pro<20, 2, PRO_AFF>(p, st);
+  if (p.groups > 1) launch_ws_fused<5, 2, false, false, false, PRO_AFF, false>(p, st);
+  else if (stats) launch_ws_fused<5, 1, false, false, false, PRO_AFF, true>(p, st);
+  else launch_ws_fused<5, 1, false, false, false, PRO_AFF, false>(p, st);
   MD_CHECK_LAUNCH("md_gemm_affine");
   return MD_OK;
 }

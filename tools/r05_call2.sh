@@ -8,7 +8,7 @@ mkdir -p $O
 cd $R
 timeout 420 python -m pytest tests/test_fused_norm_gpu.py -x -q > $O/pytest_fused.log 2>&1; echo "fused tests rc=$?"; tail -25 $O/pytest_fused.log
 MD_ITERS=20 timeout 200 python tools/bench_kernels.py fused > $O/bench_fused.log 2>&1; grep -v amdgpu $O/bench_fused.log
-timeout 600 python -m pytest tests/test_unets_gpu.py tests/test_blocks_gpu.py -x -q > $O/pytest_unets.log 2>&1; echo "unets rc=$?"; tail -6 $O/pytest_unets.log
+timeout 900 python -m pytest tests/test_unets_gpu.py tests/test_blocks_gpu.py tests/test_full_size_gpu.py tests/test_e2e_parity_gpu.py -x -q > $O/pytest_unets.log 2>&1; echo "unets rc=$?"; tail -6 $O/pytest_unets.log
 for r in 1 2; do for f in 0 1; do
   MD_FUSE_NORMS=$f timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc 2>/dev/null | python -c "
 import json,sys
