@@ -236,7 +236,9 @@ def _external_video(path, want):
     except ImportError:
         pass
     raise RuntimeError(f"{path}: its video codec needs an external decoder and none of PyAV / cv2 / imageio is installed.  Pass a "
-                       "directory of frame images, a .gif / .webp / .npy, or a Motion-JPEG .mp4 (what save_videos_grid writes)")
+                       "directory of frame images, a .gif / .webp / .npy, or a Motion-JPEG .mp4 (what save_videos_grid writes).  On any "
+                       "machine that has one of those packages, `python -m mikudance_amd.io_utils convert <clip>.mp4 <clip>.mjpeg.mp4` "
+                       "(or `... <clip>_frames/`) re-encodes the clip once into a form this reader decodes natively")
 
 
 _IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".webp")
@@ -358,3 +360,27 @@ def resize_depth(depth_map, output_shape):
         filtered = ndi.gaussian_filter(image, sigma, cval=0, mode="mirror")
     out = ndi.zoom(filtered, [1 / f for f in factors], order=1, mode="mirror", cval=0, grid_mode=True)
     return np.clip(out, image.min(), image.max())
+
+
+# ------------------------------------------------------------------------------------------------ one-time conversion of codec'd clips
+def convert_video(src, dst, quality=95):
+    """Re-encode `src` (anything read_frames can decode on THIS machine: H.264 needs PyAV / cv2 / imageio here) into a form read_frames
+    decodes natively everywhere: `dst` ending in .mp4 -> Motion-JPEG mp4 at the source's frame rate; anything else -> a directory of
+    numbered PNG frames.  The reference's demo clips (demo_samples/poses/*.mp4, H.264) need this once before the drop-in script can read
+    them on a box without a video decoder: point tgt_pose_path / tgt_face_path / tgt_hand_path of configs/inference/inference_video.yaml at
+    the converted files (reference src/utils/util.py:106-137 reads through PyAV).  Returns the number of frames written."""
+    frames = read_frames(src)
+    if str(dst).lower().endswith(".mp4"):
+        write_mjpeg_mp4(frames, str(dst), fps=get_fps(src) or 8, quality=quality)
+    else:
+        os.makedirs(str(dst), exist_ok=True)
+        for i, im in enumerate(frames):
+            im.save(os.path.join(str(dst), f"{i:06d}.png"))
+    return len(frames)
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) != 4 or sys.argv[1] != "convert":
+        sys.exit("usage: python -m mikudance_amd.io_utils convert <source video> <target .mp4 (Motion-JPEG) | target directory (PNG frames)>")
+    print(f"{convert_video(sys.argv[2], sys.argv[3])} frames -> {sys.argv[3]}")

@@ -50,11 +50,11 @@ def _temporal_conv(x, w3, bias, frames, residual=None):
     On the (clips, frames, H*W, C) view the temporal convolution IS a 3 x 1 filter over an image whose rows are the frames:
     md_conv_nhwc_f16 with kw = 1 -- one implicit GEMM with K = 3 C, the three taps summed in the fp32 accumulator and rounded
     ONCE like the reference's Conv3d (three accumulating token GEMMs, the form used until round 3, rounded the partial sums to
-    fp16 twice more).  Clips beyond the kernel's 2^24-pixel image limit fall back to that form."""
+    fp16 twice more).  Clips beyond the kernel's image limits (2^24 pixels, 2^32 elements) fall back to that form."""
     B, H, W, C = x.shape
     hw = H * W
     cout = w3.shape[0]
-    if frames * hw < (1 << 24):
+    if frames * hw < (1 << 24) and frames * hw * C < (1 << 32):           # both limits of md_conv_nhwc_f16's tap arithmetic
         out = ops.conv3x3(x.view(B // frames, frames, hw, C), w3, cout, bias=bias, kw=1,
                           residual=tokens(residual) if residual is not None else None)
         return out.view(B, H, W, cout)

@@ -173,3 +173,24 @@ def test_temporal_decoder_16_frames_at_64x64_latents_vs_oracle():
     assert tuple(got.shape) == (frames, 3, 512, 512)
     r, c = rel_l2(got.float(), want), cosine(got.float(), want)
     assert r < 3e-2 and c > 0.999, (r, c)
+
+
+def test_temporal_decoder_16_frames_at_the_headline_size_vs_oracle():
+    """--video_decoder at the size the reference runs it for the headline configuration: chunks of 16 frames at 96 x 96 latents -> 768 x 768
+    pixels (src/pipelines/pipeline_mikudance.py:132-150).  The widest 3 x 1 implicit GEMM sees an image of 16 rows x 589 824 pixels
+    (9.4 M pixels, 1.2 G elements: inside both limits of the conv's tap arithmetic).  Timing record: profiles/r05_vae_temporal.json."""
+    from mikudance_amd import AutoencoderKLTemporalDecoder
+    vae = AutoencoderKLTemporalDecoder()
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed=31)
+    for k in sd:
+        if k.endswith("mix_factor"):
+            sd[k] = torch.tensor([0.7 if "mid" in k else -0.4])
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.to("cuda", dtype=torch.float16)
+    frames = 16
+    z = torch.randn(frames, 4, 96, 96, generator=torch.Generator().manual_seed(5)).half().float()
+    want = _oracle_on_gpu(O.vae_temporal_decode, sd, z, frames)
+    got = vae.decode(z.cuda().half(), num_frames=frames).sample
+    assert tuple(got.shape) == (frames, 3, 768, 768)
+    r, c = rel_l2(got.float(), want), cosine(got.float(), want)
+    assert r < 3e-2 and c > 0.999, (r, c)
