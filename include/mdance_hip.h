@@ -155,7 +155,8 @@ int md_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const v
                          const int* kv_index, int B, int H, int D, int Lq, int Lk, int kv_stride, float scale,
                          void* stream);
 
-/* Attention over FRAMES for every (clip-half, pixel, head); rows are (b*F + frame)*HW + pixel.  F <= 32.
+/* Attention over FRAMES for every (clip-half, pixel, head); rows are (b*F + frame)*HW + pixel.  F <= 32.  O must not overlap Q, K or V
+ * (column-sliced siblings of one wider row-major buffer, e.g. q | k | v of one GEMM, are fine): checked, MD_ERR_ARG otherwise.
  * src/models/motion_module.py:364-439 (VersatileAttention, Temporal mode). */
 int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
                                   int ldo, int NB, int F, int HW, int H, int D, float scale, void* stream);

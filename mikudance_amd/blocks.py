@@ -62,8 +62,13 @@ class Affine(nn.Module):
 
 
 def tokens(x):
-    """[pixels, C] view of an NHWC tensor -- also of a channel slice of a wider one (row pitch = the wider tensor's channel count)."""
-    return x.flatten(0, -2)
+    """[pixels, C] VIEW of an NHWC tensor -- also of a channel slice of a wider one (row pitch = the wider tensor's channel count).
+    Used for operands and for `out=` destinations alike, so it must never be a copy: flatten() silently copies when the outer
+    dimensions cannot be merged, and a kernel would then write into a temporary."""
+    t = x.flatten(0, -2)
+    if t.data_ptr() != x.data_ptr() or t.stride(-1) != 1:
+        raise ops._lib.MdanceHipError(f"tokens(): shape {tuple(x.shape)} strides {tuple(x.stride())} has no [pixels, C] view")
+    return t
 
 
 def groupnorm_frames(x, w, b, eps, silu, gn_frames=1):

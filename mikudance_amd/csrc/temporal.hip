@@ -235,7 +235,11 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TemporalParams 
   const int region = nchunk * 16;
   for (int c = t; c < nchunk; c += 256) {
 #endif
-    const int cl = min(c, nchunk - 1);
+#ifdef TA_Q_REGISTERS
+    const int cl = min(c, nchunk - 1);                 // the rounded-up region has chunks past the last one
+#else
+    const int cl = c;
+#endif
     const int j = cl / spr;
     int sl = cl - j * spr;
     if (sl == spr - 1) sl = 0;                         // padding slot: any valid address
@@ -436,6 +440,15 @@ extern "C" int md_temporal_attention_fwd_f16(const void* Q, int ldq, const void*
   MD_CHECK_ARG(F >= 1 && F <= 32, "md_temporal_attention_fwd: F=%d frames, the positional-encoding table holds 32", F);
   MD_CHECK_ARG(D % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "md_temporal_attention_fwd: D and strides must be multiples of 8");
   MD_CHECK_ARG(H >= 1 && H <= 8 && (H & (H - 1)) == 0, "md_temporal_attention_fwd: H=%d heads must be a power of two <= 8", H);
+  {
+    // O must not overlap Q / K / V: a workgroup's output rows are other workgroups' inputs (every pixel's F frames are spread over the
+    // token matrix), and the matrix-core kernel parks O in the LDS image of Q
+    const size_t rows = (size_t)NB * F * HW;
+    auto lo = [](const void* q) { return reinterpret_cast<uintptr_t>(q); };
+    auto hi = [&](const void* q, int ld) { return reinterpret_cast<uintptr_t>(q) + ((rows - 1) * (size_t)ld + (size_t)H * D) * 2; };
+    auto apart = [&](const void* q, int ld) { return hi(O, ldo) <= lo(q) || hi(q, ld) <= lo(O) || (ld == ldo && ((lo(q) > lo(O) ? lo(q) - lo(O) : lo(O) - lo(q)) / 2) % ldo >= (size_t)H * D && ((lo(q) > lo(O) ? lo(q) - lo(O) : lo(O) - lo(q)) / 2) % ldo + (size_t)H * D <= (size_t)ldo); };
+    MD_CHECK_ARG(apart(Q, ldq) && apart(K, ldk) && apart(V, ldv), "md_temporal_attention_fwd: O must not overlap Q, K or V");
+  }
   TemporalParams p;
   p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;

@@ -127,7 +127,9 @@ class MikuDanceVideoPipeline:
         ref_latents         (1, F, 22, h, w) 20 VAE-latent guidance channels + 2 scene-motion channels
         image_prompt_embeds (2, L, D) = [zeros, CLIP tokens] when guidance_scale > 1, else (1, L, D)
         eta, generator      DDIM's stochastic variant (reference :152-171 -> scheduler.step(eta=, generator=)): one N(0, 1) draw of
-                            the latents' shape and dtype per step from `generator` (on ITS device, like diffusers' randn_tensor)
+                            the latents' shape and dtype per step from `generator` (on ITS device, like diffusers' randn_tensor).
+                            The kernels compute in fp16: the draw is ROUNDED TO fp16 on its way into md_cfg_ddim_step_eta, so an
+                            fp32-dtype caller does not get a noise stream bit-comparable with an fp32 reference run
         returns latents (1, 4, F, h, w) in the input dtype.
         """
         dev = latents.device
@@ -326,6 +328,11 @@ class MikuDanceVideoPipeline:
         # no behaviour to reproduce: the windows are evaluated one at a time here, which is what the sum over a batch would be.
         if context_batch_size < 1:
             raise ValueError(f"context_batch_size must be >= 1, got {context_batch_size}")
+        if context_batch_size > 1 and not getattr(self, "_warned_context_batch", False):
+            import warnings
+            warnings.warn("context_batch_size > 1: the windows of a context batch are evaluated one at a time (the reference itself "
+                          "fails for two or more windows per batch, pipeline_mikudance.py:662); results are those of context_batch_size = 1")
+            self._warned_context_batch = True
         height = height or 768
         width = width or 768
         device = self._execution_device

@@ -332,7 +332,10 @@ def test_attention_via_gemm_vt(dev):
 
 
 @pytest.mark.parametrize("F_,HW,D,NB", [(4, 16, 8, 2), (16, 9, 40, 2), (6, 5, 32, 2), (24, 4, 80, 2), (32, 3, 160, 2), (30, 7, 40, 2), (16, 5, 80, 2), (16, 6, 160, 2),
-                                        (8, 7, 160, 2), (5, 11, 40, 2), (13, 3, 80, 2), (16, 7, 40, 1), (3, 5, 160, 3)])
+                                        (8, 7, 160, 2), (5, 11, 40, 2), (13, 3, 80, 2), (16, 7, 40, 1), (3, 5, 160, 3),
+                                        # frame counts that are no multiple of 16 at every head width: the Q / K / V images are packed back to
+                                        # back in LDS and the DMA lanes past the last chunk are switched off, not rounded to 1-KiB rows
+                                        (7, 9, 40, 2), (29, 5, 80, 1), (13, 5, 160, 2), (31, 3, 160, 1)])
 def test_temporal_attention(dev, F_, HW, D, NB):
     H = 8
     C = H * D
@@ -408,6 +411,21 @@ def test_window_accumulate_and_ddim(dev):
 def _drnd(dev, *shape, seed=0, scale=1.0):
     g = torch.Generator(device=dev).manual_seed(seed)
     return (torch.randn(*shape, generator=g, device=dev) * scale).half()
+
+
+def test_temporal_attention_refuses_an_output_that_overlaps_its_inputs(dev):
+    """O aliasing Q / K / V is not supported (every pixel's frames are spread over the token matrix; the matrix-core kernel parks O in
+    the LDS image of Q): MD_ERR_ARG, while column-sliced siblings of one buffer (q | k | v | o of one allocation) are fine."""
+    from mikudance_amd._lib import MdanceHipError
+    NB, F_, HW, H, D = 2, 16, 9, 8, 40
+    C = H * D
+    buf = rnd(NB * F_ * HW, 4 * C, seed=3).to(dev)
+    q, k, v, o = buf[:, :C], buf[:, C:2 * C], buf[:, 2 * C:3 * C], buf[:, 3 * C:]
+    want = ops.temporal_attention(q, k, v, NB, F_, HW, H, D)
+    assert torch.equal(ops.temporal_attention(q, k, v, NB, F_, HW, H, D, out=o), want)
+    for bad in (q, k, v):
+        with pytest.raises(MdanceHipError, match="overlap"):
+            ops.temporal_attention(q, k, v, NB, F_, HW, H, D, out=bad)
 
 
 def _close_dev(got, ref, rtol=1e-2, atol=1e-3, what=""):
