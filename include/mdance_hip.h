@@ -95,49 +95,34 @@ int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const void* gamma,
 int md_layernorm_f16(const void* x, void* y, void* y2, const void* gamma, const void* beta, const void* add, int M,
                      int C, float eps, int add_mode, int add_row_begin, int rows_per_frame, int frames, void* stream);
 
-/* LayerNorm FOLDED into the Linear that consumes it: C = epi(LayerNorm(A; gamma, beta, eps) . W^T + bias) computed from the RAW rows
+/* LayerNorm FOLDED into the Linear that consumes it: C = LayerNorm(A; gamma, beta, eps) . W^T + bias [+ rowadd] computed from the RAW rows
  * of A, the normalised tensor never touching HBM.  The caller folds once per layer (mikudance_amd/packing.py ln_fold):
  *   Wf[n][k] = fp16(gamma[k] W[n][k]),   sc = fp32 [2][N]:  sc[0][n] = sum_k Wf[n][k],  sc[1][n] = sum_k beta[k] W[n][k] + bias[n]
- * and the kernel evaluates rstd_m * (A[m] . Wf[n] - mu_m * sc[0][n]) + sc[1][n].  Row statistics: `stats` = fp32 [M][2] holding
- * (rstd_m, -mu_m * rstd_m) as written by the launch that PRODUCED A (md_gemm_stats_f16 / md_gemm_affine_f16 with a stats pointer), or
- * NULL -- then the kernel takes the exact two-pass (mu, rstd) of each row itself from the rows as they stream through LDS (plain
- * epilogue only).  rowadd / rows_per_group as in md_gemm_f16 (the motion module's query-only positional encoding as a per-frame row
- * term); act = MD_ACT_NONE, or MD_ACT_GEGLU with supplied statistics (Wf rows in the GEGLU packing, sc in the same row order).
- * Only shapes of the W-stationary streaming kernel exist (K = 320 on >= 32768 rows: the 96 x 96 level): md_gemm_ln_plan(M, N, K, act, epi)
- * returns 1 when this entry point has a kernel for the problem (epi bit 1: rowadd, bit 3: statistics supplied), 0 when the caller has to
- * run md_layernorm_f16 + md_gemm_f16 on the unfolded weights; md_gemm_ln_f16 itself fails (MD_ERR_ARG) on anything else -- there is no
- * silent fallback.  Replaces norm2 -> attn2.to_q and norm3 -> ff.net.0 (src/models/attention.py:131-157,339-365;
- * src/models/mutual_mix_attention.py:203-275) and norms[i] -> to_q / to_k / to_v, ff_norm -> ff.net.0 of the motion module
- * (src/models/motion_module.py:245-272). */
+ * and the kernel evaluates rstd_m * (A[m] . Wf[n] - mu_m * sc[0][n]) + sc[1][n] with the exact two-pass (mu, rstd) of each row taken
+ * from the rows as they stream through LDS.  rowadd / rows_per_group as in md_gemm_f16 (the motion module's query-only positional
+ * encoding as a per-frame row term); act must be MD_ACT_NONE.  Only shapes of the W-stationary streaming kernel exist (K = 320, N a
+ * multiple of 320, >= 32768 rows: the 96 x 96 level): md_gemm_ln_plan(M, N, K, act, epi) returns 1 when this entry point has a kernel for
+ * the problem (epi as md_gemm_plan), 0 when the caller has to run md_layernorm_f16 + md_gemm_f16 on the unfolded weights;
+ * md_gemm_ln_f16 itself fails (MD_ERR_ARG) on anything else -- there is no silent fallback.  Replaces norm2 -> attn2.to_q
+ * (src/models/attention.py:131-141,339-347; src/models/mutual_mix_attention.py:203-263) and norms[i] -> to_q / to_k / to_v of the
+ * motion module (src/models/motion_module.py:245-268, 364-439). */
 int md_gemm_ln_plan(int M, int N, int K, int act, int epi);
-int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, const float* stats, void* C, int ldc, int M, int N, int K,
-                   float eps, const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
-
-/* md_gemm_f16 (bias / row-broadcast / residual epilogue, no activation, no transpose) that ALSO leaves the LayerNorm statistics of its
- * output rows -- stats[m] = (rstd_m, -mean_m * rstd_m), exact two-pass over the row as rounded to fp16, rstd = rsqrt(var + eps) -- for the
- * md_gemm_ln_f16 launch that consumes C: 8 bytes per row instead of a LayerNorm pass.  N = K = 320 on >= 32768 rows (one column group of
- * the streaming kernel: whole output rows in one workgroup); md_gemm_stats_plan says whether the kernel exists (epi as md_gemm_plan).
- * The producers of the hidden state between the sub-layers of a transformer block: attn1 / attn2 / temporal to_out.0 + residual
- * (src/models/attention.py:105-157; src/models/motion_module.py:245-272). */
-int md_gemm_stats_plan(int M, int N, int K, int epi);
-int md_gemm_stats_f16(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, const void* bias,
-                      const void* residual, int ldr, const void* rowadd, int ldra, int rows_per_group, float eps, float* stats,
-                      void* stream);
+int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, void* C, int ldc, int M, int N, int K, float eps,
+                   const void* rowadd, int ldra, int rows_per_group, int act, void* stream);
 
 /* GroupNorm in front of a Linear / 1x1 conv without materialising the normalised tensor.  md_groupnorm_table_f16 runs the statistics
  * sweep only and writes table = fp32 [B][2][C]: scale[b][c] = rstd * gamma[c], shift[b][c] = beta[c] - mean * scale;
  * md_gemm_affine_f16 computes C = (A * scale[image] + shift[image], rounded to fp16) . W^T + bias, image = row / rows_per_image,
  * applying the affine to the rows as they stream through LDS: bit-identical to md_groupnorm_ld_nhwc_f16 (silu = 0, two-sweep form)
- * followed by md_gemm_f16.  A may be a channel slice (lda >= K).  `stats` (may be NULL): LayerNorm statistics of the OUTPUT rows as in
- * md_gemm_stats_f16, epsilon `eps`.  md_gemm_affine_plan: bit 0 = the kernel exists for the shape (K = 320, N a multiple of 320,
- * >= 32768 rows, rows_per_image % 16 == 0), bit 1 = it can emit statistics (N = 320).  Replaces norm -> proj_in of Transformer3DModel /
- * Transformer2DModel (src/models/transformer_3d.py:60-68,121-137; src/models/transformer_2d.py:296-321) and of the motion module's
+ * followed by md_gemm_f16.  A may be a channel slice (lda >= K).  md_gemm_affine_plan: 1 when the kernel exists for the shape (K = 320,
+ * N a multiple of 320, >= 32768 rows, rows_per_image % 16 == 0).  Replaces norm -> proj_in of Transformer3DModel / Transformer2DModel
+ * (src/models/transformer_3d.py:60-68,121-137; src/models/transformer_2d.py:296-321) and of the motion module's
  * TemporalTransformer3DModel (src/models/motion_module.py:121-124,159-170). */
 int md_groupnorm_table_f16(const void* x, int ldx, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
                            float* table, void* workspace, size_t ws_bytes, void* stream);
 int md_gemm_affine_plan(int M, int N, int K, int rows_per_image);
 int md_gemm_affine_f16(const void* A, int lda, const float* table, int rows_per_image, const void* W, void* C, int ldc, int M, int N,
-                       int K, const void* bias, float eps, float* stats, void* stream);
+                       int K, const void* bias, void* stream);
 
 /* MAN: y = InstanceNorm(x) * (1 + gamma) + beta; gamma_beta is (B, HW, 2C) = [gamma | beta].
  * src/models/man_module.py:23-33. */

@@ -30,12 +30,10 @@ SIGNATURES = {
     "md_instnorm_spade_ld_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_float, P]),
     "md_layernorm_f16": (c_int, [P, P, P, P, P, P, c_int, c_int, c_float, c_int, c_int, c_int, c_int, P]),
     "md_gemm_ln_plan": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "md_gemm_ln_f16": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, c_int, c_int, P]),
-    "md_gemm_stats_plan": (c_int, [c_int, c_int, c_int, c_int]),
-    "md_gemm_stats_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int, c_float, P, P]),
+    "md_gemm_ln_f16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, c_int, c_int, P]),
     "md_groupnorm_table_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
     "md_gemm_affine_plan": (c_int, [c_int, c_int, c_int, c_int]),
-    "md_gemm_affine_f16": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_float, P, P]),
+    "md_gemm_affine_f16": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, P]),
     "md_instnorm_spade_f16": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P]),
     "md_attention_fwd_f16": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_float, P]),

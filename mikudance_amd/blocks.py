@@ -180,54 +180,40 @@ def _pack_ff(ff, dev, pk, prefix="ff"):
 
 
 # Normalisations that never reach HBM (tests switch this off to compare against the literal operator sequence).  Where the
-# W-stationary streaming GEMM serves the consumer (K = 320 / 640 on >= 32768 tokens: the 96 x 96 and 48 x 48 levels), a LayerNorm is
-# folded into its Linear (md_gemm_ln_f16) and a SiLU-free GroupNorm is applied to the rows inside the GEMM (md_gemm_affine_f16);
-# everywhere else the literal pair of operators runs.  norm1 stays a kernel of its own: its output IS the bank / K-V operand.
+# W-stationary streaming GEMM serves the consumer with a plain epilogue (K = 320 on >= 32768 tokens: the 96 x 96 level), a LayerNorm is
+# folded into its Linear (md_gemm_ln_f16: norm2 -> to_q, the motion module's norms -> q|k|v) and a SiLU-free GroupNorm is applied to the
+# rows inside the GEMM (md_gemm_affine_f16: norm -> proj_in); everywhere else -- the other levels, the GEGLU consumers of norm3 / ff_norm
+# -- the literal pair of operators runs (the plan queries say no: measured, profiles/r05_ab_fused_norms*.log).  norm1 stays a kernel of
+# its own: its output IS the bank / K-V operand.
 FUSE_NORMS = __import__("os").environ.get("MD_FUSE_NORMS", "1") != "0"      # MD_FUSE_NORMS=0: A/B runs against the literal operator pairs
 
 
-def ln_linear(pk, h, norm, lin, bias=None, rowadd=None, rows_per_group=0, act=ops.ACT_NONE, eps=1e-5, stats=None):
-    """LayerNorm(pk[norm + 'w'], pk[norm + 'b']) -> Linear(pk[lin], pk[bias]) [+ row term] [GEGLU] on the token matrix h.
-    stats: the row statistics of h left by the launch that produced it (row_stats_for / gemm(stats_out=)), or None."""
+def ln_linear(pk, h, norm, lin, bias=None, rowadd=None, rows_per_group=0, act=ops.ACT_NONE, eps=1e-5):
+    """LayerNorm(pk[norm + 'w'], pk[norm + 'b']) -> Linear(pk[lin], pk[bias]) [+ row term] [GEGLU] on the token matrix h."""
     M, K = h.shape
     w = pk[lin]
-    if FUSE_NORMS and ops.gemm_ln_plan(M, w.shape[0], K, act, rowadd is not None, stats is not None):
+    if FUSE_NORMS and ops.gemm_ln_plan(M, w.shape[0], K, act, rowadd is not None):
         fk = lin + ":ln"
         if fk not in pk:                  # folded once per layer, on first use (only the layers the fused kernel serves pay for it)
             pk[fk] = packing.ln_fold(w, None if bias is None else pk[bias], pk[norm + "w"], pk[norm + "b"])
         wf, sc = pk[fk]
-        return ops.gemm_ln(h, wf, sc, eps=eps, rowadd=rowadd, rows_per_group=rows_per_group, act=act, stats=stats)
+        return ops.gemm_ln(h, wf, sc, eps=eps, rowadd=rowadd, rows_per_group=rows_per_group, act=act)
     n = ops.layernorm(h, pk[norm + "w"], pk[norm + "b"], eps=eps)
     return ops.gemm(n, w, bias=None if bias is None else pk[bias], rowadd=rowadd, rows_per_group=rows_per_group, act=act)
 
 
-def row_stats_for(M, N, K, device):
-    """A side buffer for the LayerNorm statistics of the rows a [M, K] x [N, K]^T GEMM is about to produce, when that GEMM can emit them
-    (and the fused normalisations are on); None otherwise -- the consumer then takes the statistics itself or runs the literal LayerNorm."""
-    return ops.new_row_stats(M, device) if FUSE_NORMS and ops.gemm_stats_plan(M, N, K) else None
-
-
-def gn_linear(x, gamma, beta, eps, w, bias, want_stats=False):
-    """GroupNorm(32, eps) (no SiLU) -> 1 x 1 conv / Linear on the tokens of x (B, H, W, C); returns [B*H*W, N] (and, with want_stats, the
-    LayerNorm statistics of the output rows or None)."""
+def gn_linear(x, gamma, beta, eps, w, bias):
+    """GroupNorm(32, eps) (no SiLU) -> 1 x 1 conv / Linear on the tokens of x (B, H, W, C); returns [B*H*W, N]."""
     B, C = x.shape[0], x.shape[-1]
-    M, N = x.numel() // C, w.shape[0]
-    plan = ops.gemm_affine_plan(M, N, C, M // B) if FUSE_NORMS else 0
-    st = None
-    if plan:
-        if want_stats and plan & 2:
-            st = ops.new_row_stats(M, x.device)
-        out = ops.gemm_affine(x, ops.groupnorm_table(x, gamma, beta, GROUPS, eps), w, bias=bias, stats_out=st)
-    else:
-        if want_stats:
-            st = row_stats_for(M, N, C, x.device)
-        out = ops.gemm(tokens(ops.groupnorm(x, gamma, beta, GROUPS, eps)), w, bias=bias, stats_out=st)
-    return (out, st) if want_stats else out
+    M = x.numel() // C
+    if FUSE_NORMS and ops.gemm_affine_plan(M, w.shape[0], C, M // B):
+        return ops.gemm_affine(x, ops.groupnorm_table(x, gamma, beta, GROUPS, eps), w, bias=bias)
+    return ops.gemm(tokens(ops.groupnorm(x, gamma, beta, GROUPS, eps)), w, bias=bias)
 
 
-def _run_ff(pk, h, norm, prefix="ff", stats=None):
+def _run_ff(pk, h, norm, prefix="ff"):
     """h + FeedForward(LayerNorm(h)) (GEGLU)."""
-    g = ln_linear(pk, h, norm, prefix + "1", bias=prefix + "1b", act=ops.ACT_GEGLU, stats=stats)
+    g = ln_linear(pk, h, norm, prefix + "1", bias=prefix + "1b", act=ops.ACT_GEGLU)
     return ops.gemm(g, pk[prefix + "2"], bias=pk[prefix + "2b"], residual=h)
 
 
@@ -321,9 +307,6 @@ class TransformerBlock(_Packed):
             self._kv_cache = (cross, ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True), {})
         kv2 = self._kv_cache[1:]
         zf = min(cross.zero_frames, B) if ZERO_CONTEXT_SKIP else 0
-        # The out-projections leave the LayerNorm statistics of the rows they write (8 bytes per row) where the kernel can: norm2 and
-        # norm3 then cost nothing but an epilogue in their consumers (ln_linear).
-        st = row_stats_for(h.shape[0], C, C, h.device)
         if zf:
             # frames with an all-zero context: cross-attention == to_out bias.  It rides on the attn1 out-projection as a
             # per-frame row-broadcast term, and those rows skip norm2 / to_q / attention / to_out altogether.
@@ -332,19 +315,16 @@ class TransformerBlock(_Packed):
                 tab = torch.zeros((B, C), device=h.device, dtype=torch.float16)
                 tab[:zf] = pk["o2b"]
                 kv2[2][(B, zf)] = tab
-            h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h, rowadd=tab, rows_per_group=L, stats_out=st)
+            h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h, rowadd=tab, rows_per_group=L)
         else:
-            h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h, stats_out=st)
+            h = ops.gemm(a, pk["o1"], bias=pk["o1b"], residual=h)
         # cross attention to the CLIP tokens
         if zf < B:
             hs = h[zf * L:]
-            sts = st[zf * L:] if st is not None else None
-            q2 = ln_linear(pk, hs, "n2", "q2", stats=sts)
+            q2 = ln_linear(pk, hs, "n2", "q2")
             a2 = ops.attention(q2, kv2[0], kv2[1], B - zf, H, D, L, cross.lk, kv_stride=cross.lpad, kv_index=cross.index[zf:])
-            if sts is not None and not ops.gemm_stats_plan(hs.shape[0], C, C):
-                st = sts = None                                            # these rows are about to change and their statistics would go stale
-            ops.gemm(a2, pk["o2"], bias=pk["o2b"], residual=hs, out=hs, stats_out=sts)    # in place: each element is read and written by one thread
-        return _run_ff(pk, h, "n3", stats=st)
+            ops.gemm(a2, pk["o2"], bias=pk["o2b"], residual=hs, out=hs)    # in place: each element is read and written by one thread
+        return _run_ff(pk, h, "n3")
 
 
 class SpatialTransformer(_Packed):
@@ -453,16 +433,15 @@ class MotionModule(_Packed):
             raise ValueError(f"window of {f} frames exceeds the positional-encoding table ({self.max_len})")
         _, Hh, Ww, C = x.shape
         HW, H = Hh * Ww, self.heads
-        h, st = gn_linear(x, pk["nw"], pk["nb"], 1e-6, pk["pi"], pk["pib"], want_stats=True)
+        h = gn_linear(x, pk["nw"], pk["nb"], 1e-6, pk["pi"], pk["pib"])
         for i in range(2):
             tab = pk.get(("peq", i, nb, f))
             if tab is None:
                 tab = pk[("peq", i, nb, f)] = pk[f"peq{i}"][:f].repeat(nb, 1).contiguous()       # one row per (clip-half, frame)
-            qkv = ln_linear(pk, h, f"n{i}", f"qkv{i}", rowadd=tab, rows_per_group=HW, stats=st)
+            qkv = ln_linear(pk, h, f"n{i}", f"qkv{i}", rowadd=tab, rows_per_group=HW)
             a = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, f, HW, H, C // H)
-            st = row_stats_for(h.shape[0], C, C, h.device)
-            h = ops.gemm(a, pk[f"o{i}"], bias=pk[f"o{i}b"], residual=h, stats_out=st)
-        h = _run_ff(pk, h, "fn", stats=st)
+            h = ops.gemm(a, pk[f"o{i}"], bias=pk[f"o{i}b"], residual=h)
+        h = _run_ff(pk, h, "fn")
         if out is not None:
             ops.gemm(h, pk["po"], bias=pk["pob"], residual=tokens(x), out=tokens(out))
             return out

@@ -602,117 +602,68 @@ static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
   hipLaunchKernelGGL((wsgemm_kernel<10, 4, 1, false, false, true>), dim3(256), dim3(512), smem, stream, p);
 }
 
-// ---- fused-normalisation flavours of the streaming kernel (gemm_ws.h: PRO_LNF / PRO_LNS / PRO_AFF prologues, STATS epilogue) --------
-// K = 320 only (the 96 x 96 level), M >= 32768 rows in whole 16-row tiles, no residual on the consumers.  Measured and NOT built in: the
-// K = 640 forms (the loader waves' in-LDS work per 20-KiB tile doubles the tile time: profiles/r05_ab_fused_norms_first_build.log) and
-// GEGLU with in-kernel statistics (its memory waves are VALU bound by the GELU).
-static bool ws_fused_rows(int M, int lda, int ldc) { return M >= 32768 && M % 16 == 0 && lda % 8 == 0 && ldc % 8 == 0; }
+// ---- fused-normalisation flavours of the streaming kernel (gemm_ws.h: PRO_LNF / PRO_AFF prologues) -----------------------------------
+// K = 320 only (the 96 x 96 level), plain epilogue, N a multiple of 320, M >= 32768 rows in whole 16-row tiles, no residual.  Measured and
+// NOT built in (profiles/r05_ab_fused_norms*.log): the K = 640 forms, GEGLU, and row statistics handed from the producer to the consumer.
+static bool ws_fused_shape(int M, int N, int K, int lda, int ldc) {
+  return K == 320 && N % 320 == 0 && N / 320 <= 8 && M >= 32768 && M % 16 == 0 && lda % 8 == 0 && ldc % 8 == 0;
+}
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <int CB, int TPR, bool RES, bool RA, bool GEGLU, int PRO, bool STATS>
+template <int TPR, bool RA, int PRO>
 static void launch_ws_fused(const WsParams& p, hipStream_t stream) {
-  using Cfg = WsCfg<10, CB, TPR>;
-  md_ensure_dynamic_lds<wsgemm_kernel<10, CB, TPR, RES, RA, GEGLU, PRO, STATS>>(Cfg::SMEM);
-  hipLaunchKernelGGL((wsgemm_kernel<10, CB, TPR, RES, RA, GEGLU, PRO, STATS>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
+  using Cfg = WsCfg<10, 5, TPR>;
+  md_ensure_dynamic_lds<wsgemm_kernel<10, 5, TPR, false, RA, false, PRO>>(Cfg::SMEM);
+  hipLaunchKernelGGL((wsgemm_kernel<10, 5, TPR, false, RA, false, PRO>), dim3(256), dim3(512), Cfg::SMEM, stream, p);
 }
 
-static void ws_groups(WsParams& p, int gc) {
-  p.groups = p.N / gc;
-  p.spx = 32 / p.groups;
-  p.streams = 8 * p.spx;
-}
-
-// epi: bit 0 residual, bit 1 row-broadcast operand, bit 3 (8) row statistics supplied.  1 when md_gemm_ln_f16 has a kernel for the
-// problem (dense operands assumed), else 0: the caller then runs md_layernorm_f16 + md_gemm_f16 on the unfolded weights.
+// epi: bit 0 residual, bit 1 row-broadcast operand (as md_gemm_plan).  1 when md_gemm_ln_f16 has a kernel for the problem (dense operands
+// assumed), else 0: the caller then runs md_layernorm_f16 + md_gemm_f16 on the unfolded weights.
 extern "C" int md_gemm_ln_plan(int M, int N, int K, int act, int epi) {
-  if (K != 320 || !ws_fused_rows(M, K, 8) || (epi & 1)) return 0;
-  if (act == ACT_GEGLU) return (epi & 8) && !(epi & 2) && N % 256 == 0 && N / 256 <= 16;
-  return act == ACT_NONE && N % 320 == 0 && N / 320 <= 8;
+  return act == ACT_NONE && !(epi & 1) && ws_fused_shape(M, N, K, K, N);
 }
 
-extern "C" int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, const float* stats, void* C, int ldc, int M, int N, int K,
-                              float eps, const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
-  MD_CHECK_ARG(md_gemm_ln_plan(M, N, K, act, (rowadd ? 2 : 0) | (stats ? 8 : 0)) && ws_fused_rows(M, lda, ldc),
-               "md_gemm_ln: no fused LayerNorm kernel for M=%d N=%d K=%d act=%d rowadd=%d stats=%d (ask md_gemm_ln_plan first)", M, N, K, act,
-               rowadd != nullptr, stats != nullptr);
-  MD_CHECK_ARG(al16(A) && al16(Wf) && al16(C) && al16(sc) && al16(rowadd) && (!rowadd || (ldra % 8 == 0 && rows_per_group > 0)) &&
-                   (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
-               "md_gemm_ln: operands must be 16-byte aligned (stats 8-byte; ldra %% 8 == 0, rows_per_group > 0 with rowadd)");
+extern "C" int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const float* sc, void* C, int ldc, int M, int N, int K, float eps,
+                              const void* rowadd, int ldra, int rows_per_group, int act, void* stream) {
+  MD_CHECK_ARG(act == ACT_NONE && ws_fused_shape(M, N, K, lda, ldc),
+               "md_gemm_ln: no fused LayerNorm kernel for M=%d N=%d K=%d act=%d (ask md_gemm_ln_plan first)", M, N, K, act);
+  MD_CHECK_ARG(al16(A) && al16(Wf) && al16(C) && al16(sc) && al16(rowadd) && (!rowadd || (ldra % 8 == 0 && rows_per_group > 0)),
+               "md_gemm_ln: operands must be 16-byte aligned (ldra %% 8 == 0, rows_per_group > 0 with rowadd)");
   WsParams p = {};
   p.A = (const half_t*)A; p.W = (const half_t*)Wf; p.C = (half_t*)C; p.rowadd = (const half_t*)rowadd;
   p.lda = lda; p.ldc = ldc; p.ldra = ldra; p.M = M; p.N = N; p.rows_per_group = rowadd ? rows_per_group : 1;
-  p.lnf = sc; p.eps = eps; p.stats_in = stats;
+  p.lnf = sc; p.eps = eps;
+  p.groups = N / 320; p.spx = 32 / p.groups; p.streams = 8 * p.spx;
   hipStream_t st = (hipStream_t)stream;
-  if (act == ACT_GEGLU) {
-    ws_groups(p, 256);
-    launch_ws_fused<4, 1, false, false, true, PRO_LNS, false>(p, st);
+  if (p.groups > 1) {
+    if (rowadd) launch_ws_fused<2, true, PRO_LNF>(p, st);
+    else launch_ws_fused<2, false, PRO_LNF>(p, st);
   } else {
-    ws_groups(p, 320);
-    const bool multi = p.groups > 1, ra = rowadd != nullptr;
-#define MD_LN_CASE(TPR_, RA_)                                                           \
-  if (stats) launch_ws_fused<5, TPR_, false, RA_, false, PRO_LNS, false>(p, st);        \
-  else launch_ws_fused<5, TPR_, false, RA_, false, PRO_LNF, false>(p, st)
-    if (multi && ra) { MD_LN_CASE(2, true); }
-    else if (multi) { MD_LN_CASE(2, false); }
-    else if (ra) { MD_LN_CASE(1, true); }
-    else { MD_LN_CASE(1, false); }
-#undef MD_LN_CASE
+    if (rowadd) launch_ws_fused<1, true, PRO_LNF>(p, st);
+    else launch_ws_fused<1, false, PRO_LNF>(p, st);
   }
   MD_CHECK_LAUNCH("md_gemm_ln");
   return MD_OK;
 }
 
-// epi: bit 0 residual, bit 1 row-broadcast operand.  1 when md_gemm_stats_f16 has a kernel: N = K = 320 (one column group: the store
-// waves hold whole output rows).
-extern "C" int md_gemm_stats_plan(int M, int N, int K, int epi) { return K == 320 && N == 320 && ws_fused_rows(M, K, N); }
-
-extern "C" int md_gemm_stats_f16(const void* A, int lda, const void* W, void* C, int ldc, int M, int N, int K, const void* bias, const void* residual,
-                                 int ldr, const void* rowadd, int ldra, int rows_per_group, float eps, float* stats, void* stream) {
-  MD_CHECK_ARG(md_gemm_stats_plan(M, N, K, 0) && ws_fused_rows(M, lda, ldc) && stats != nullptr,
-               "md_gemm_stats: no kernel that emits row statistics for M=%d N=%d K=%d (ask md_gemm_stats_plan first)", M, N, K);
-  MD_CHECK_ARG(al16(A) && al16(W) && al16(C) && al16(bias) && al16(residual) && al16(rowadd) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0 &&
-                   (!residual || ldr % 8 == 0) && (!rowadd || (ldra % 8 == 0 && rows_per_group > 0)),
-               "md_gemm_stats: operands must be 16-byte aligned (stats 8-byte), pitches multiples of 8");
-  MD_CHECK_ARG(!residual || residual != C || ldr == ldc, "md_gemm_stats: in-place residual needs ldr == ldc");
-  WsParams p = {};
-  p.A = (const half_t*)A; p.W = (const half_t*)W; p.C = (half_t*)C; p.bias = (const half_t*)bias; p.residual = (const half_t*)residual;
-  p.rowadd = (const half_t*)rowadd;
-  p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldra = ldra; p.M = M; p.N = N; p.rows_per_group = rowadd ? rows_per_group : 1;
-  p.stats_out = stats; p.eps_out = eps;
-  ws_groups(p, 320);
-  hipStream_t st = (hipStream_t)stream;
-  if (residual && rowadd) launch_ws_fused<5, 1, true, true, false, PRO_NONE, true>(p, st);
-  else if (residual) launch_ws_fused<5, 1, true, false, false, PRO_NONE, true>(p, st);
-  else if (rowadd) launch_ws_fused<5, 1, false, true, false, PRO_NONE, true>(p, st);
-  else launch_ws_fused<5, 1, false, false, false, PRO_NONE, true>(p, st);
-  MD_CHECK_LAUNCH("md_gemm_stats");
-  return MD_OK;
-}
-
-// bit 0: md_gemm_affine_f16 has a kernel for the problem; bit 1: it can also emit the row statistics of its output (N = 320)
 extern "C" int md_gemm_affine_plan(int M, int N, int K, int rows_per_image) {
-  if (rows_per_image <= 0 || rows_per_image % 16 || M % rows_per_image || K != 320 || N % 320 || N / 320 > 8 || !ws_fused_rows(M, K, N)) return 0;
-  return N == 320 ? 3 : 1;
+  return rows_per_image > 0 && rows_per_image % 16 == 0 && M % rows_per_image == 0 && ws_fused_shape(M, N, K, K, N);
 }
 
 extern "C" int md_gemm_affine_f16(const void* A, int lda, const float* table, int rows_per_image, const void* W, void* C, int ldc, int M, int N,
-                                  int K, const void* bias, float eps, float* stats, void* stream) {
-  const int plan = md_gemm_affine_plan(M, N, K, rows_per_image);
-  MD_CHECK_ARG(plan && ws_fused_rows(M, lda, ldc) && (!stats || (plan & 2)),
-               "md_gemm_affine: no fused kernel for M=%d N=%d K=%d rows_per_image=%d stats=%d (ask md_gemm_affine_plan first)", M, N, K, rows_per_image,
-               stats != nullptr);
-  MD_CHECK_ARG(al16(A) && al16(W) && al16(C) && al16(table) && al16(bias) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
-               "md_gemm_affine: operands must be 16-byte aligned (stats 8-byte)");
+                                  int K, const void* bias, void* stream) {
+  MD_CHECK_ARG(rows_per_image > 0 && rows_per_image % 16 == 0 && M % rows_per_image == 0 && ws_fused_shape(M, N, K, lda, ldc),
+               "md_gemm_affine: no fused kernel for M=%d N=%d K=%d rows_per_image=%d (ask md_gemm_affine_plan first)", M, N, K, rows_per_image);
+  MD_CHECK_ARG(al16(A) && al16(W) && al16(C) && al16(table) && al16(bias), "md_gemm_affine: operands must be 16-byte aligned");
   MD_CHECK_ARG(A != C, "md_gemm_affine: in place is not supported");
   WsParams p = {};
   p.A = (const half_t*)A; p.W = (const half_t*)W; p.C = (half_t*)C; p.bias = (const half_t*)bias;
   p.lda = lda; p.ldc = ldc; p.M = M; p.N = N; p.rows_per_group = 1;
-  p.aff = table; p.rows_per_image = rows_per_image; p.stats_out = stats; p.eps_out = eps;
-  ws_groups(p, 320);
+  p.aff = table; p.rows_per_image = rows_per_image;
+  p.groups = N / 320; p.spx = 32 / p.groups; p.streams = 8 * p.spx;
   hipStream_t st = (hipStream_t)stream;
-  if (p.groups > 1) launch_ws_fused<5, 2, false, false, false, PRO_AFF, false>(p, st);
-  else if (stats) launch_ws_fused<5, 1, false, false, false, PRO_AFF, true>(p, st);
-  else launch_ws_fused<5, 1, false, false, false, PRO_AFF, false>(p, st);
+  if (p.groups > 1) launch_ws_fused<2, false, PRO_AFF>(p, st);
+  else launch_ws_fused<1, false, PRO_AFF>(p, st);
   MD_CHECK_LAUNCH("md_gemm_affine");
   return MD_OK;
 }

@@ -62,9 +62,6 @@ struct WsParams {
   float eps;         // PRO_LNF: LayerNorm epsilon
   const float* aff;  // PRO_AFF: [M / rows_per_image][2][K] fp32 -- per (image, input channel) scale then shift (GroupNorm apply)
   int rows_per_image;
-  const float* stats_in;   // PRO_LNS: [M][2] fp32 (rstd, -mean rstd) of the rows of A, written by the kernel that produced A (STATS)
-  float* stats_out;        // STATS: [M][2] fp32 (rstd, -mean rstd) of the rows of C as rounded to fp16, LayerNorm epsilon eps_out
-  float eps_out;
 };
 
 // Prologues.  Both rest on the fact that a stage of this kernel holds WHOLE rows of A (all of K) in LDS before the matrix core reads it.
@@ -84,16 +81,14 @@ struct WsParams {
 //            gn_apply_kernel followed by this GEMM, minus the 4 bytes per element the normalised tensor cost.  The table of the lane's
 //            columns lives in registers and changes with the image, so PRO_AFF streams walk CONTIGUOUS row blocks (a stream meets at
 //            most ceil(rows per stream / rows per image) + 1 images) instead of the interleaved tiles of the other flavours.
-//   PRO_LNS  the same fold with the row statistics SUPPLIED: the launch that produced A (a single-column-group launch of this kernel,
-//            STATS = true: its store waves hold whole output rows) has left (rstd, -mean rstd) per row in an [M][2] fp32 side buffer -- 8
-//            bytes per 640-byte row -- and loader wave 0 DMAs a tile's 16 pairs into the LDS ring next to the A tile.  No statistics
-//            arithmetic in this kernel at all: this is what lets the GEGLU flavour (whose memory waves are VALU bound by the GELU) take
-//            the fold, applied by its COMPUTE waves, and drop the bias adds from the memory waves.
-// STATS (store waves, single column group only): a row's N / 8 pieces sit in 8 ADJACENT lanes (row = lane / 8, pieces lane % 8 + 8 i)
-// instead of running lane-linearly through the tile, so the exact two-pass (mean, rstd) of the ROUNDED row -- what the consumer's
-// LayerNorm would compute from the fp16 tensor -- is a sum over the lane's own 5 pieces and three 8-lane exchanges.  Stores are then
-// 128-byte row segments (8 lanes x 16 B) instead of 1-KiB runs.
-enum { PRO_NONE = 0, PRO_LNF = 1, PRO_AFF = 2, PRO_LNS = 3 };
+// Measured in round 5 and REMOVED again (profiles/r05_ab_fused_norms_statistics_chain.log): row statistics emitted by the producing
+// out-projection's store waves (a row's pieces in 8 adjacent lanes, exact two-pass, 8 bytes per row to a side buffer) and consumed by the
+// fold (16 pairs DMA'd beside the A tile), which let the GEGLU flavour take the fold.  The consumers became free (q|k|v 0.246 vs 0.261 ms,
+// GEGLU 0.626 vs 0.618 + a 0.082-ms LayerNorm), the producers paid +0.02 ms each for ~110 VALU per tile and lane in the store waves, and in
+// the denoising loop the folded GEGLU lost the memory-side-cache warmth the LayerNorm pass used to leave behind (0.653 vs 0.561 ms per
+// launch): +0.5 % end to end where in-kernel statistics on the plain consumers alone are worth more.  Every K = 640 form and GEGLU with
+// in-kernel statistics lost outright (the loader waves' work per 20-KiB tile, redone by each of 5-15 column groups, doubles the tile time).
+enum { PRO_NONE = 0, PRO_LNF = 1, PRO_AFF = 2 };
 
 template <int KS, int CB, int TPR>
 struct WsCfg {
@@ -107,8 +102,8 @@ struct WsCfg {
   static constexpr int CS_LD = GC + 4;            // fp32 staging pitch (floats): rows shift by 4 banks
   static constexpr int CSTAGE = TR * CS_LD * 4;   // one staging tile; 2 * TPR of them (double buffered rounds)
   static constexpr int OSTAGE = GEGLU_CFG ? 2 * 2048 : 0;   // GEGLU: fp16 pieces finished by the loader waves, shipped by the store waves
-  static constexpr int SSLOT = 32;                          // float2 per (round, tile) slot of the statistics ring: 16 rows + the DMA's upper 32 lanes
-  static constexpr int SSTAGE = 14 * TPR * SSLOT * 8;       // PRO_LNF: 4 rounds deep (written in round r-1, read in r and r+1); PRO_LNS: NR + 2
+  static constexpr int SSLOT = TR;                          // float2 per (round, tile) slot of the statistics ring: one per row
+  static constexpr int SSTAGE = 4 * TPR * SSLOT * 8;        // PRO_LNF: (a, b) per row, 4 rounds deep (written in round r-1, read in r and r+1)
   static constexpr int NR_FIT = (160 * 1024 - 2 * TPR * CSTAGE - OSTAGE - SSTAGE) / RSTAGE;
   static constexpr int NR = NR_FIT > 12 ? 12 : NR_FIT;       // ring depth in rounds
   static constexpr int DPT = STAGE / 1024;        // DMA wave-instructions per tile
@@ -118,8 +113,7 @@ struct WsCfg {
   static constexpr int SPL = CHUNKS / 128;        // ... per lane of the two store waves
   static constexpr int PD = KS <= 10 ? 3 : 6;     // A fragments in flight per compute wave (register budget: 256 per wave)
   static_assert(DPT % 2 == 0 && CHUNKS % 128 == 0, "tile must split evenly over the loader / store waves");
-  static constexpr int SR = NR + 2;                         // PRO_LNS: rounds of statistics in the ring (DMA'd NR - 1 ahead, read up to round + 1)
-  static_assert(NR >= 3 && (NR - 2) * TPR * (PER + 1) <= 63 && SR <= 14, "ring depth / vmcnt immediate");
+  static_assert(NR >= 3 && (NR - 2) * TPR * PER <= 63, "ring depth / vmcnt immediate");
   static constexpr int RES_DEPTH = KS == 20 ? WS_RES_DEPTH_640 : WS_RES_DEPTH;
   static_assert(RES_DEPTH % TPR == 0, "residual buffers are indexed statically per unrolled round");
 };
@@ -144,7 +138,6 @@ struct WsGegluPiece {
   int row, hcol;            // staging row, staging column of h (g sits 32 columns further)
   float bh[8], bg[8];
 };
-template <bool BIAS = true>    // BIAS = false (PRO_LNF): the compute waves have already applied the folded LayerNorm, bias included
 __device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, const WsGegluPiece& q) {
   const float* s = cs + q.row * cs_ld + q.hcol;
   const floatx4 h0 = *reinterpret_cast<const floatx4*>(s), h1 = *reinterpret_cast<const floatx4*>(s + 4);
@@ -152,35 +145,33 @@ __device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, co
   half8_t o;
   float2_t gl[4];                         // pairs: the GELU polynomial runs on packed fp32, the four chains of a piece side by side
 #pragma unroll
-  for (int j = 0; j < 4; ++j) gl[j] = BIAS ? float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]} : float2_t{g0[j], g1[j]};
+  for (int j = 0; j < 4; ++j) gl[j] = float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]};
   gelu_fast2_x<4>(gl);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    o[j] = (half_t)((BIAS ? h0[j] + q.bh[j] : h0[j]) * gl[j].x);
-    o[j + 4] = (half_t)((BIAS ? h1[j] + q.bh[j + 4] : h1[j]) * gl[j].y);
+    o[j] = (half_t)((h0[j] + q.bh[j]) * gl[j].x);
+    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gl[j].y);
   }
   return o;
 }
 
-template <int KS, int CB, int TPR, bool RES, bool RA, bool GEGLU = false, int PRO = PRO_NONE, bool STATS = false>
+template <int KS, int CB, int TPR, bool RES, bool RA, bool GEGLU = false, int PRO = PRO_NONE>
 __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
-  constexpr bool LN = PRO == PRO_LNF || PRO == PRO_LNS;          // the folded LayerNorm is applied in the epilogue
-  static_assert(!(GEGLU && PRO == PRO_LNF), "GEGLU takes the fold only with supplied statistics (PRO_LNS): its memory waves are VALU bound");
-  static_assert(!STATS || (!GEGLU && TPR == 1), "STATS: single column group (whole output rows in the store waves)");
+  constexpr bool LN = PRO == PRO_LNF;                             // the folded LayerNorm is applied in the epilogue (store waves)
+  static_assert(PRO == PRO_NONE || !GEGLU, "GEGLU has no prologue flavour: its memory waves are VALU bound by the GELU");
   static_assert(!GEGLU || (CB == 4 && TPR == 1 && !RES && !RA), "GEGLU: 2 h + 2 g column blocks per compute wave, one tile per round, bias only");
   static_assert(PRO == PRO_NONE || !RES, "prologue flavours: no residual (their consumers have none)");
 
   static_assert(PRO != PRO_AFF || (!RA && !GEGLU), "PRO_AFF: bias only");
   using Cfg = WsCfg<KS, CB, TPR>;
-  // statistics slot of (round r, tile u): PRO_LNF 4 rounds deep, PRO_LNS NR + 2
-  auto lslot_of = [](int r, int u) { return ((PRO == PRO_LNS ? r % Cfg::SR : (r & 3)) * TPR + u) * Cfg::SSLOT; };
+  auto lslot_of = [](int r, int u) { return ((r & 3) * TPR + u) * Cfg::SSLOT; };      // statistics slot of (round r, tile u)
   constexpr int K = Cfg::K, CPR = Cfg::CPR, GC = Cfg::GC, TR = Cfg::TR, STAGE = Cfg::STAGE, RSTAGE = Cfg::RSTAGE, NR = Cfg::NR,
                 CS_LD = Cfg::CS_LD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
   float* cst = reinterpret_cast<float*>(smem + NR * RSTAGE);       // staging tile (round parity, tile u): index (r & 1) * TPR + u
   char* ost = smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE;          // GEGLU: 2 x 2 KiB of finished fp16 pieces, loader -> store waves
-  float2_t* lst = reinterpret_cast<float2_t*>(smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE + Cfg::OSTAGE);   // PRO_LNF / PRO_LNS: (a, b) of round r, tile u, row: lslot_of(r, u) + row
+  float2_t* lst = reinterpret_cast<float2_t*>(smem + NR * RSTAGE + 2 * TPR * Cfg::CSTAGE + Cfg::OSTAGE);   // PRO_LNF: (a, b) of round r, tile u, row: lslot_of(r, u) + row
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // workgroup -> (XCD, column group, row stream): the G groups of one row stream share an XCD (blockIdx % 8)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -211,7 +202,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       gp.row = id / (GC / 16);
       const int oc = (id % (GC / 16)) * 8;
       gp.hcol = 64 * (oc >> 5) + (oc & 31);
-      if constexpr (!LN) {
+      {
         const half8_t b0 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         const half8_t b1 = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + gp.hcol + 32) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -232,22 +223,11 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     }
     const int row = lane & 15, kq = lane >> 4;
     const int rbase = row * CPR, sw = ws_swz<CPR>(row);
-    // PRO_LNS + GEGLU: s[n], c[n] of this lane's 4 * CB staging columns (the memory waves are bound by the GELU: the fold is applied here)
-    floatx4 lsv[GEGLU && LN ? CB : 1], lcv[GEGLU && LN ? CB : 1];
-    if constexpr (GEGLU && LN) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        lsv[cb] = *reinterpret_cast<const floatx4*>(p.lnf + n0 + wave * 16 * CB + cb * 16 + 4 * kq);
-        lcv[cb] = *reinterpret_cast<const floatx4*>(p.lnf + p.N + n0 + wave * 16 * CB + cb * 16 + 4 * kq);
-      }
-    }
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): weights are in registers before the loop
     constexpr int PD = Cfg::PD;
     constexpr int SWB = CPR == 40 ? 3 : 4, P = (1 << SWB) / 4;
-    auto compute_tile = [&](const char* st, int buf, int lslot) {
+    auto compute_tile = [&](const char* st, int buf) {
       floatx4 acc[CB];
-      float2_t ab = {1.f, 0.f};
-      if constexpr (GEGLU && LN) ab = lst[lslot + row];      // (rstd, -mu rstd) of this lane's row, DMA'd beside the A tile
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
       // slot (4ks + kq) ^ sw: the swizzle only touches the low SWB bits, so there are P = 2^SWB / 4 distinct per-lane base
@@ -270,10 +250,6 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                       //     ahead of that step's CB MFMAs
       }
       // acc[cb][r] = C[m = row][n = wave*16CB + cb*16 + 4*kq + r]
-      if constexpr (GEGLU && LN) {
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[cb] = ab.x * acc[cb] + (ab.y * lsv[cb] + lcv[cb]);
-      }
       float* cs = cst + buf * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
@@ -283,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       const char* st = ring + (r % NR) * RSTAGE;
 #pragma unroll
       for (int u = 0; u < TPR; ++u)
-        if (r * TPR + u < my_tiles) compute_tile(st + u * STAGE, (r & 1) * TPR + u, lslot_of(r, u));
+        if (r * TPR + u < my_tiles) compute_tile(st + u * STAGE, (r & 1) * TPR + u);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging stores WRITTEN before the hand-over barrier
     }
     __builtin_amdgcn_s_barrier();                   // b_rounds
@@ -359,8 +335,6 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       }
     };
     if constexpr (PRO == PRO_AFF) load_table((tile0 * TR) / p.rows_per_image);      // before the first DMA is issued
-    const float* ssp = PRO == PRO_LNS ? p.stats_in + (size_t)tile0 * TR * 2 + (lane & 31) : nullptr;
-    const size_t sstep = (size_t)tstep * TR * 2;
     auto issue_round = [&](int q) {                 // called with q = 0, 1, 2, ... in order; tiles are issued in order too
       char* st = ring + (q % NR) * RSTAGE;
 #pragma unroll
@@ -372,12 +346,6 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
             __builtin_amdgcn_global_load_lds((gptr_t)sp[i], (lptr_t)(st + u * STAGE + base * 16), 16, 0, 0);
             sp[i] += astep;
           }
-          if constexpr (PRO == PRO_LNS) {
-            if (lw == 0) {                          // the tile's 16 (a, b) pairs = 32 floats, one per lane (the upper 32 lanes repeat them)
-              __builtin_amdgcn_global_load_lds((gptr_t)ssp, (lptr_t)(lst + lslot_of(q, u)), 4, 0, 0);
-              ssp += sstep;
-            }
-          }
         }
       }
     };
@@ -387,11 +355,9 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     for (int r = 0; r < rounds; ++r) {
       // round r must have landed before the barrier.  Issued so far: rounds <= r+NR-2; all of r+1 .. r+NR-2 are FULL rounds
       // (TPR tiles, TPR*PER pieces each) as long as none of them is the last one -- otherwise simply drain.
-      if (r + NR - 2 < rounds - 1) {
-        if (PRO == PRO_LNS && lw == 0) wait_vmcnt<(NR - 2) * TPR * (Cfg::PER + 1)>();      // this wave also issues the statistics piece of every tile
-        else wait_vmcnt<(NR - 2) * TPR * Cfg::PER>();
-      } else wait_vmcnt<0>();
-      if constexpr (PRO == PRO_LNF || PRO == PRO_AFF) {   // round r has landed (this wave's rows): normalise / take the statistics before the hand-over
+      if (r + NR - 2 < rounds - 1) wait_vmcnt<(NR - 2) * TPR * Cfg::PER>();
+      else wait_vmcnt<0>();
+      if constexpr (PRO != PRO_NONE) {              // round r has landed (this wave's rows): normalise / take the statistics before the hand-over
         char* st = ring + (r % NR) * RSTAGE;
 #pragma unroll
         for (int u = 0; u < TPR; ++u) {
@@ -411,7 +377,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       if (r + NR - 1 < rounds) issue_round(r + NR - 1);   // into stage (r - 1) % NR
       if constexpr (GEGLU) {
         if (r >= 1) {                               // this wave's piece of tile r-1 -> LDS (shipped by a store wave after b_{r+1})
-          const half8_t o = ws_geglu_piece<!LN>(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          const half8_t o = ws_geglu_piece(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
           *reinterpret_cast<half8_t*>(ost + ((r - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -419,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     }
     __builtin_amdgcn_s_barrier();                   // b_rounds
     if constexpr (GEGLU) {
-      const half8_t o = ws_geglu_piece<!LN>(cst + ((rounds - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+      const half8_t o = ws_geglu_piece(cst + ((rounds - 1) & 1) * (TR * CS_LD), CS_LD, gp);
       *reinterpret_cast<half8_t*>(ost + ((rounds - 1) & 1) * 2048 + (lw * 64 + lane) * 16) = o;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                 // b_{rounds + 1}
@@ -440,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           cp_ld += cstep;
         }
         if (r >= 1 && r <= rounds) {                                    // own piece of tile r-1
-          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece<!LN>(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
+          *reinterpret_cast<half8_t*>(cp_own) = ws_geglu_piece(cst + ((r - 1) & 1) * (TR * CS_LD), CS_LD, gp);
           cp_own += cstep;
         }
       }
@@ -460,8 +426,8 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
         const int id = i * 128 + sid;
-        prow[i] = STATS ? sid >> 3 : id / CPRO;                         // STATS: a row's pieces in 8 adjacent lanes
-        pcol[i] = STATS ? ((sid & 7) + 8 * i) * 8 : (id % CPRO) * 8;
+        prow[i] = id / CPRO;
+        pcol[i] = (id % CPRO) * 8;
         const half8_t bv = p.bias ? *reinterpret_cast<const half8_t*>(p.bias + n0 + pcol[i]) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) biasf[i][j] = (float)bv[j];
@@ -513,7 +479,6 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
         // all LDS reads first (one latency per tile, not one per piece), then the arithmetic
         floatx4 ca[SPL], cb2[SPL];
         float2_t ab[LN ? SPL : 1];
-        half8_t orow[STATS ? SPL : 1];
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
           ca[i] = *reinterpret_cast<const floatx4*>(cs + prow[i] * CS_LD + pcol[i]);
@@ -547,37 +512,6 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
           *reinterpret_cast<half8_t*>(cp[i]) = o;
           cp[i] += cstep;
-          if constexpr (STATS) orow[i] = o;
-        }
-#if defined(WS_ABL_STATS) && WS_ABL_STATS == 1          // diagnostic build: the row-per-8-lanes piece map alone, no statistics
-        if constexpr (false) {
-#else
-        if constexpr (STATS) {
-#endif
-          // exact two-pass (mean, rstd) of the row AS STORED (fp16): this lane's SPL pieces + the 7 other lanes of the row
-          float sum = 0.f;
-#pragma unroll
-          for (int i = 0; i < SPL; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; j += 2)
-              sum = __builtin_amdgcn_fdot2(half2_t{orow[i][j], orow[i][j + 1]}, half2_t{(half_t)1.0f, (half_t)1.0f}, sum, false);
-          sum = ws_sum8(sum);
-          const float mu = sum * (1.0f / GC);
-          float sq = 0.f;
-#pragma unroll
-          for (int i = 0; i < SPL; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float d = (float)orow[i][j] - mu;
-              sq += d * d;
-            }
-          sq = ws_sum8(sq);
-          const float a = rsqrtf(sq * (1.0f / GC) + p.eps_out);
-#if defined(WS_ABL_STATS) && WS_ABL_STATS == 2          // diagnostic build: the arithmetic without the 8-byte stores
-          asm volatile("" ::"v"(a), "v"(mu));
-#else
-          if ((sid & 7) == 0) *reinterpret_cast<float2_t*>(p.stats_out + (size_t)(m0 + prow[0]) * 2) = float2_t{a, -mu * a};
-#endif
         }
       };
       if constexpr (RES) {

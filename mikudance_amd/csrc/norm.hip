@@ -83,9 +83,39 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
   }
 }
 
+// Images of many slabs (the AutoencoderKL at 768 x 768: 576 slabs per image; the temporal decoder's clip-wide GroupNorm: ~9000): every
+// workgroup of the apply sweep re-reducing all partial sums of its image is O(slabs) work per workgroup and O(slabs^2) per image -- 290 of
+// the 421 ms of a temporal-decoder chunk in round 4's form (profiles/r05_vae_temporal.json).  Above GN_FIN_SLABS slabs ONE small launch
+// reduces them (8 lanes per group, k = j, j + 8, ..., three exchanges) and leaves (mean, rstd) per (image, group) for the apply sweep.
+#ifndef GN_FIN_SLABS
+#define GN_FIN_SLABS 128
+#endif
+__global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pilot, float* __restrict__ fin, int HW, int C, int G, int nslab,
+                                   float eps) {
+  const int b = blockIdx.x, g = threadIdx.x >> 3, j = threadIdx.x & 7;
+  if (g >= G) return;
+  float a = 0.f, c2 = 0.f;
+  const float* pp = part + ((size_t)b * nslab * G + g) * 2;
+  for (int k = j; k < nslab; k += 8) {
+    a += pp[(size_t)k * G * 2];
+    c2 += pp[(size_t)k * G * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    a += __shfl_xor(a, o, 64);
+    c2 += __shfl_xor(c2, o, 64);
+  }
+  if (j == 0) {
+    const float n = (float)HW * (float)(C / G);
+    const float mu = a / n;
+    fin[((size_t)b * G + g) * 2] = pilot[(size_t)b * G + g] + mu;
+    fin[((size_t)b * G + g) * 2 + 1] = rsqrtf(fmaxf(c2 / n - mu * mu, 0.f) + eps);
+  }
+}
+
 __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restrict__ part, const float* __restrict__ pilot, const half_t* __restrict__ gamma,
                                 const half_t* __restrict__ beta, int HW, int C, int ldx, int G, int R, int slab, int nslab, float eps, int silu,
-                                int zigzag) {
+                                int zigzag, const float* __restrict__ fin) {
   __shared__ float mean_s[64], rstd_s[64];
   const int cch = C >> 3;
   const int cc = threadIdx.x % cch, r = threadIdx.x / cch;
@@ -94,6 +124,11 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
   const int b = zigzag ? gridDim.y - 1 - blockIdx.y : blockIdx.y, sl = zigzag ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const int cpg = C / G;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    if (fin) {                                            // many slabs: reduced once by gn_finalize_kernel
+      mean_s[g] = fin[((size_t)b * G + g) * 2];
+      rstd_s[g] = fin[((size_t)b * G + g) * 2 + 1];
+      continue;
+    }
     float a = 0.f, c2 = 0.f;
     const float* pp = part + ((size_t)b * nslab * G + g) * 2;
     for (int k = 0; k < nslab; ++k) {
@@ -243,7 +278,7 @@ static void gn_geometry(int B, int HW, int C, int& R, int& slab, int& nslab) {
 extern "C" size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
   int R, slab, nslab;
   gn_geometry(B, HW, C, R, slab, nslab);
-  return ((size_t)B * nslab * G * 2 + (size_t)B * G) * sizeof(float);       // partial sums + one pilot per (image, group)
+  return ((size_t)B * nslab * G * 2 + (size_t)B * G * 3) * sizeof(float);   // partial sums + one pilot + (mean, rstd) per (image, group)
 }
 
 extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G, float eps,
@@ -281,9 +316,13 @@ extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const v
   const dim3 grid(nslab, B), block(cch * R);
   const size_t sh = (size_t)2 * R * C * sizeof(float);
   float* pilot = (float*)workspace + (size_t)B * nslab * G * 2;
+  float* fin = nslab > GN_FIN_SLABS ? pilot + (size_t)B * G : nullptr;
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, pilot, HW, C, ldx, G, R, slab, nslab);
+  if (fin)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(8 * G), 0, (hipStream_t)stream, (const float*)workspace, (const float*)pilot, fin, HW, C, G, nslab,
+                       eps);
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (const float*)workspace, (const float*)pilot,
-                     (const half_t*)gamma, (const half_t*)beta, HW, C, ldx, G, R, slab, nslab, eps, silu, zigzag);
+                     (const half_t*)gamma, (const half_t*)beta, HW, C, ldx, G, R, slab, nslab, eps, silu, zigzag, (const float*)fin);
   MD_CHECK_LAUNCH("md_groupnorm");
   return MD_OK;
 }
@@ -293,21 +332,28 @@ extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const v
 // proj_in of Transformer3DModel / the motion module's temporal transformer -- applies x * scale + shift to the rows it has just
 // streamed into LDS, so the normalised tensor never exists in HBM: 2 bytes per element (this sweep) instead of 6.
 __global__ void gn_table_kernel(const float* __restrict__ part, const float* __restrict__ pilot, const half_t* __restrict__ gamma,
-                                const half_t* __restrict__ beta, float* __restrict__ table, int HW, int C, int G, int nslab, float eps) {
+                                const half_t* __restrict__ beta, float* __restrict__ table, int HW, int C, int G, int nslab, float eps,
+                                const float* __restrict__ fin) {
   const int b = blockIdx.x, cpg = C / G;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const int g = c / cpg;
-    float a = 0.f, c2 = 0.f;
-    const float* pp = part + ((size_t)b * nslab * G + g) * 2;
-    for (int k = 0; k < nslab; ++k) {
-      a += pp[(size_t)k * G * 2];
-      c2 += pp[(size_t)k * G * 2 + 1];
+    float mean, rstd;
+    if (fin) {                                            // many slabs: the same (mean, rstd) the apply sweep would use
+      mean = fin[((size_t)b * G + g) * 2];
+      rstd = fin[((size_t)b * G + g) * 2 + 1];
+    } else {
+      float a = 0.f, c2 = 0.f;
+      const float* pp = part + ((size_t)b * nslab * G + g) * 2;
+      for (int k = 0; k < nslab; ++k) {
+        a += pp[(size_t)k * G * 2];
+        c2 += pp[(size_t)k * G * 2 + 1];
+      }
+      const float n = (float)HW * (float)cpg;
+      const float mu = a / n;                             // mean of x - k
+      mean = pilot[(size_t)b * G + g] + mu;
+      rstd = rsqrtf(fmaxf(c2 / n - mu * mu, 0.f) + eps);
     }
-    const float n = (float)HW * (float)cpg;
-    const float mu = a / n;                               // mean of x - k
-    const float var = fmaxf(c2 / n - mu * mu, 0.f);
-    const float mean = pilot[(size_t)b * G + g] + mu;
-    const float sc = rsqrtf(var + eps) * (float)gamma[c];
+    const float sc = rstd * (float)gamma[c];
     table[(size_t)b * 2 * C + c] = sc;
     table[(size_t)b * 2 * C + C + c] = __builtin_fmaf(-mean, sc, (float)beta[c]);
   }
@@ -326,8 +372,12 @@ extern "C" int md_groupnorm_table_f16(const void* x, int ldx, const void* gamma,
   const size_t sh = (size_t)2 * R * C * sizeof(float);
   float* pilot = (float*)workspace + (size_t)B * nslab * G * 2;
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, sh, (hipStream_t)stream, (const half_t*)x, (float*)workspace, pilot, HW, C, ldx, G, R, slab, nslab);
+  float* fin = nslab > GN_FIN_SLABS ? pilot + (size_t)B * G : nullptr;
+  if (fin)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(8 * G), 0, (hipStream_t)stream, (const float*)workspace, (const float*)pilot, fin, HW, C, G, nslab,
+                       eps);
   hipLaunchKernelGGL(gn_table_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (const float*)pilot, (const half_t*)gamma,
-                     (const half_t*)beta, table, HW, C, G, nslab, eps);
+                     (const half_t*)beta, table, HW, C, G, nslab, eps, (const float*)fin);
   MD_CHECK_LAUNCH("md_groupnorm_table");
   return MD_OK;
 }

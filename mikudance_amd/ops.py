@@ -57,20 +57,9 @@ def _pixel_pitch(x, name, align=8):
     return ld
 
 
-def gemm_stats_plan(M, N, K):
-    """True when a GEMM of this shape can leave the LayerNorm statistics of its output rows (gemm(..., stats_out=))."""
-    return bool(_lib.load().md_gemm_stats_plan(M, N, K, 0))
-
-
-def new_row_stats(M, device):
-    """fp32 [M, 2] side buffer: (rstd, -mean * rstd) per row, written by gemm(stats_out=) / gemm_affine(stats_out=), read by gemm_ln(stats=)."""
-    return torch.empty((M, 2), device=device, dtype=torch.float32)
-
-
 def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, transpose_out=False, out=None,
-         ldc_t=None, stats_out=None, stats_eps=1e-5):
-    """out[M, N] = epi(a[M, K] @ w[N, K]^T).  transpose_out: out is [N, ldc_t] (V^T for attention).
-    stats_out (fp32 [M, 2], only where gemm_stats_plan says so): also (rstd, -mean * rstd) of every output row, LayerNorm epsilon stats_eps."""
+         ldc_t=None):
+    """out[M, N] = epi(a[M, K] @ w[N, K]^T).  transpose_out: out is [N, ldc_t] (V^T for attention)."""
     lda = _rowmajor(a, "a")
     _chk(w, "w")
     M, K = a.shape
@@ -85,13 +74,6 @@ def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_
     ldr = _rowmajor(residual, "residual") if residual is not None else 0
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
     _chk(bias, "bias")
-    if stats_out is not None:
-        _chk(stats_out, "stats_out", torch.float32)
-        assert act == ACT_NONE and not transpose_out and stats_out.shape == (M, 2) and stats_out.is_contiguous()
-        _lib.call("md_gemm_stats_f16", a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias), _p(residual), ldr, _p(rowadd), ldra,
-                  rows_per_group, float(stats_eps), stats_out.data_ptr(), _st(),
-                  meta=(f"gemm M={M} N={N} K={K} +stats", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
-        return out
     _lib.call("md_gemm_f16", a.data_ptr(), lda, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias), _p(residual), ldr,
               _p(rowadd), ldra, rows_per_group, act, int(transpose_out), _st(),
               meta=(f"gemm M={M} N={N} K={K}" + (" geglu" if act == ACT_GEGLU else "") + (" T" if transpose_out else ""),
@@ -128,28 +110,25 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
     return out
 
 
-def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False, stats=False):
+def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False):
     """True when md_gemm_ln_f16 has a kernel for the problem (else: layernorm + gemm on the unfolded weights)."""
-    return bool(_lib.load().md_gemm_ln_plan(M, N, K, act, (2 if rowadd else 0) | (8 if stats else 0)))
+    return bool(_lib.load().md_gemm_ln_plan(M, N, K, act, 2 if rowadd else 0))
 
 
-def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None, stats=None):
-    """out[M, N] = epi(LayerNorm(a) @ w^T + bias) from the RAW rows of a, with (wf, sc) = packing.ln_fold(w, bias, gamma, beta).
-    stats: the (rstd, -mean * rstd) rows left by the launch that produced `a` (None: the kernel takes them itself)."""
+def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None):
+    """out[M, N] = epi(LayerNorm(a) @ w^T + bias) from the RAW rows of a, with (wf, sc) = packing.ln_fold(w, bias, gamma, beta)."""
     lda = _rowmajor(a, "a")
-    _chk(wf, "wf"); _chk(sc, "sc", torch.float32); _chk(rowadd, "rowadd"); _chk(stats, "stats", torch.float32)
+    _chk(wf, "wf"); _chk(sc, "sc", torch.float32); _chk(rowadd, "rowadd")
     M, K = a.shape
     N = wf.shape[0]
     assert wf.shape[1] == K and wf.is_contiguous() and sc.shape == (2, N) and sc.is_contiguous(), (wf.shape, sc.shape, K)
-    assert stats is None or (stats.shape == (M, 2) and stats.is_contiguous())
     if out is None:
         out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), device=a.device, dtype=F16)
     ldc = _rowmajor(out, "out")
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
-    _lib.call("md_gemm_ln_f16", a.data_ptr(), lda, wf.data_ptr(), sc.data_ptr(), _p(stats), out.data_ptr(), ldc, M, N, K, float(eps), _p(rowadd),
-              ldra, rows_per_group, act, _st(),
-              meta=(f"gemm M={M} N={N} K={K}" + (" geglu" if act == ACT_GEGLU else "") + (" ln" if stats is None else " ln(stats)"),
-                    2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
+    _lib.call("md_gemm_ln_f16", a.data_ptr(), lda, wf.data_ptr(), sc.data_ptr(), out.data_ptr(), ldc, M, N, K, float(eps), _p(rowadd), ldra,
+              rows_per_group, act, _st(),
+              meta=(f"gemm M={M} N={N} K={K}" + (" geglu" if act == ACT_GEGLU else "") + " ln", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
     return out
 
 
@@ -167,8 +146,7 @@ def _gn_workspace(x, B, HW, C, groups):
 
 
 def gemm_affine_plan(M, N, K, rows_per_image):
-    """0: no fused kernel; 1: gemm_affine exists for the shape; 3: ... and can leave row statistics (stats_out=)."""
-    return int(_lib.load().md_gemm_affine_plan(M, N, K, rows_per_image))
+    return bool(_lib.load().md_gemm_affine_plan(M, N, K, rows_per_image))
 
 
 def groupnorm_table(x, gamma, beta, groups, eps):
@@ -184,9 +162,8 @@ def groupnorm_table(x, gamma, beta, groups, eps):
     return table
 
 
-def gemm_affine(x, table, w, bias=None, out=None, stats_out=None, stats_eps=1e-5):
-    """out[B*HW, N] = fp16(x * scale[image] + shift[image]) @ w^T + bias; x (B, HW, C) / (B, H, W, C) NHWC (a channel slice is fine).
-    stats_out: as in gemm()."""
+def gemm_affine(x, table, w, bias=None, out=None):
+    """out[B*HW, N] = fp16(x * scale[image] + shift[image]) @ w^T + bias; x (B, HW, C) / (B, H, W, C) NHWC (a channel slice is fine)."""
     lda = _pixel_pitch(x, "x")
     _chk(w, "w"); _chk(bias, "bias"); _chk(table, "table", torch.float32)
     B, K = x.shape[0], x.shape[-1]
@@ -196,11 +173,8 @@ def gemm_affine(x, table, w, bias=None, out=None, stats_out=None, stats_eps=1e-5
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=F16)
     ldc = _rowmajor(out, "out")
-    _chk(stats_out, "stats_out", torch.float32)
-    assert stats_out is None or (stats_out.shape == (M, 2) and stats_out.is_contiguous())
-    _lib.call("md_gemm_affine_f16", x.data_ptr(), lda, table.data_ptr(), M // B, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias),
-              float(stats_eps), _p(stats_out), _st(),
-              meta=(f"gemm M={M} N={N} K={K} gn" + (" +stats" if stats_out is not None else ""), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
+    _lib.call("md_gemm_affine_f16", x.data_ptr(), lda, table.data_ptr(), M // B, w.data_ptr(), out.data_ptr(), ldc, M, N, K, _p(bias), _st(),
+              meta=(f"gemm M={M} N={N} K={K} gn", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
     return out
 
 

@@ -27,24 +27,7 @@ def _pitch(x, align=8):
     return ld
 
 
-def _row_stats(y16, eps):
-    """(rstd, -mean * rstd) of the rows of an fp16 matrix: what md_gemm_stats_f16 / md_gemm_affine_f16 leave for md_gemm_ln_f16."""
-    y = y16.float()
-    mu = y.mean(1)
-    rstd = torch.rsqrt(((y - mu[:, None]) ** 2).mean(1) + eps)
-    return torch.stack([rstd, -mu * rstd], 1)
-
-
-def gemm_stats_plan(M, N, K):
-    return FUSED
-
-
-def new_row_stats(M, device):
-    return torch.full((M, 2), float("nan"))            # NaN until a producer fills it: a consumer reading unwritten rows fails the comparison
-
-
-def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, transpose_out=False, out=None, ldc_t=None,
-         stats_out=None, stats_eps=1e-5):
+def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_NONE, transpose_out=False, out=None, ldc_t=None):
     assert a.dim() == 2 and a.stride(1) == 1 and a.dtype == F16 and w.dtype == F16 and w.is_contiguous()
     M, K = a.shape
     N = w.shape[0]
@@ -70,10 +53,6 @@ def gemm(a, w, bias=None, residual=None, rowadd=None, rows_per_group=0, act=ACT_
         res = torch.zeros((N, ldc_t or M), dtype=F16) if out is None else out
         res[:, :M] = acc.t().to(F16)
         return res
-    if stats_out is not None:
-        assert act == ACT_NONE and not transpose_out and stats_out.shape == (M, 2)
-        stats_out.copy_(_row_stats(acc.to(F16), stats_eps))
-        CALLS.append(("gemm_stats", (M, N, K)))
     if out is None:
         return acc.to(F16)
     assert out.shape == acc.shape and out.stride(1) == 1
@@ -154,30 +133,24 @@ def layernorm(x, gamma, beta, eps=1e-5, add=None, add_mode=0, add_row_begin=0, r
 FUSED = False
 
 
-def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False, stats=False):
-    return FUSED and not (act == ACT_GEGLU and (rowadd or not stats))
+def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False):
+    return FUSED and not (act == ACT_GEGLU and rowadd)
 
 
-def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None, stats=None):
+def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None):
     assert a.dim() == 2 and a.stride(1) == 1 and a.dtype == F16 and wf.dtype == F16 and sc.dtype == torch.float32 and sc.shape == (2, wf.shape[0])
     M, K = a.shape
     N = wf.shape[0]
     x = a.float()
-    if stats is None:
-        mu = x.mean(1, keepdim=True)
-        rstd = torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)
-        aa, bb = rstd, -mu * rstd
-    else:
-        assert stats.shape == (M, 2) and stats.is_contiguous() and torch.isfinite(stats).all(), "row statistics missing or stale"
-        assert torch.allclose(stats, _row_stats(a, eps), rtol=1e-4, atol=1e-5), "row statistics do not describe this tensor"
-        aa, bb = stats[:, :1], stats[:, 1:]
-    acc = aa * (x @ wf.float().t()) + bb * sc[0] + sc[1]              # the kernel's arithmetic: raw rows, folded weights
+    mu = x.mean(1, keepdim=True)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)
+    acc = rstd * (x @ wf.float().t() - mu * sc[0]) + sc[1]            # the kernel's arithmetic: raw rows, folded weights
     if act == ACT_GEGLU:
         q = acc.view(M, N // 64, 2, 32)
         acc = (q[:, :, 0] * F.gelu(q[:, :, 1])).reshape(M, N // 2)
     if rowadd is not None:
         acc = acc + rowadd.float()[torch.arange(M) // rows_per_group]
-    CALLS.append(("gemm_ln", (M, N, K, act, stats is not None)))
+    CALLS.append(("gemm_ln", (M, N, K, act)))
     if out is None:
         return acc.to(F16)
     out.copy_(acc.to(F16))
@@ -185,7 +158,7 @@ def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, ou
 
 
 def gemm_affine_plan(M, N, K, rows_per_image):
-    return 3 if FUSED else 0
+    return FUSED
 
 
 def groupnorm_table(x, gamma, beta, groups, eps):
@@ -200,7 +173,7 @@ def groupnorm_table(x, gamma, beta, groups, eps):
     return torch.stack([sc, sf], 1).contiguous()
 
 
-def gemm_affine(x, table, w, bias=None, out=None, stats_out=None, stats_eps=1e-5):
+def gemm_affine(x, table, w, bias=None, out=None):
     B, K = x.shape[0], x.shape[-1]
     _pitch(x)
     assert table.shape == (B, 2, K) and table.dtype == torch.float32
@@ -209,8 +182,6 @@ def gemm_affine(x, table, w, bias=None, out=None, stats_out=None, stats_eps=1e-5
     if bias is not None:
         acc = acc + bias.float()
     CALLS.append(("gemm_affine", (tuple(x.shape), tuple(x.stride()), w.shape[0])))
-    if stats_out is not None:
-        stats_out.copy_(_row_stats(acc.to(F16), stats_eps))
     if out is None:
         return acc.to(F16)
     out.copy_(acc.to(F16))
@@ -360,7 +331,7 @@ def require_gpu(t, who):
 def install(monkeypatch):
     """Replace the functions of mikudance_amd.ops by the emulations above for the duration of a test."""
     from mikudance_amd import ops
-    for name in ("gemm", "gemm_stats_plan", "new_row_stats", "gemm_ln_plan", "gemm_ln", "gemm_affine_plan", "groupnorm_table", "gemm_affine", "conv3x3", "groupnorm", "layernorm", "instnorm_spade", "attention", "softmax_rows_", "temporal_attention", "pack_nhwc",
+    for name in ("gemm", "gemm_ln_plan", "gemm_ln", "gemm_affine_plan", "groupnorm_table", "gemm_affine", "conv3x3", "groupnorm", "layernorm", "instnorm_spade", "attention", "softmax_rows_", "temporal_attention", "pack_nhwc",
                  "unpack_nhwc", "concat_channels", "window_accumulate", "cfg_ddim_step", "require_gpu"):
         monkeypatch.setattr(ops, name, globals()[name])
     del CALLS[:]

@@ -523,6 +523,20 @@ def test_groupnorm_at_config5_batch(dev):
         del ref
 
 
+@pytest.mark.parametrize("B,HW,C,inplace", [(2, 589824, 128, False), (1, 16 * 36864, 256, True), (3, 150000, 128, False)])
+def test_groupnorm_with_many_slabs_per_image(dev, B, HW, C, inplace):
+    """Images of hundreds to thousands of slabs -- the AutoencoderKL at 768 x 768 (576 slabs), the temporal decoder's clip-wide GroupNorm on
+    the (clip, frames * h * w, C) view -- take the three-launch form (statistics, ONE reduction of the partial sums, apply) instead of
+    re-reducing the partials in every workgroup of the apply sweep (round 5); a ragged last slab and the in-place form included."""
+    x = _drnd(dev, B, HW, C, seed=36) * 1.5 + 2.0
+    g, b = (1 + 0.1 * _drnd(dev, C, seed=37).float()).half(), _drnd(dev, C, seed=38)
+    ref = F.silu(F.group_norm(x.float().permute(0, 2, 1), 32, g.float(), b.float(), 1e-6)).permute(0, 2, 1)
+    out = ops.groupnorm(x, g, b, 32, 1e-6, True, out=x if inplace else None)
+    _close_dev(out, ref, what=f"groupnorm {B}x{HW}x{C}")
+    if not inplace:
+        assert torch.equal(out, ops.groupnorm(x, g, b, 32, 1e-6, True))
+
+
 def test_groupnorm_in_place(dev):
     """include/mdance_hip.h 'Aliasing': md_groupnorm_nhwc_f16 may run in place (y == x)."""
     B, HW, C = 4, 2304, 640

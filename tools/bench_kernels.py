@@ -52,44 +52,28 @@ def main(which):
             out[f"gemm {M}x{N}x{K}{' +res' if res else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9, byts / ms / 1e6)
     if "fused" in which:       # normalisation + consumer GEMM, literal operator pair against the fused entry points (round 5)
         from mikudance_amd import packing
-        for M, N, K, ra, geglu in [(294912, 960, 320, True, False), (147456, 320, 320, False, False), (294912, 2560, 320, False, True)]:
+        for M, N, K, ra in [(294912, 960, 320, True), (147456, 320, 320, False), (294912, 320, 320, False)]:
             x, w, g, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(K), rnd(K)
-            bias = rnd(N) if geglu else None
             tab = rnd(32, N) if ra else None
             rpg = M // 32
-            act = ops.ACT_GEGLU if geglu else 0
-            o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
-            wf, sc = packing.ln_fold(w, bias, g, b)
-            st = torch.stack([torch.ones(M, device=dev), torch.zeros(M, device=dev)], 1).contiguous()
+            o = torch.empty((M, N), device=dev, dtype=torch.float16)
+            wf, sc = packing.ln_fold(w, None, g, b)
             t_ln = timeit(lambda: ops.layernorm(x, g, b))
             n = ops.layernorm(x, g, b)
-            t_g = timeit(lambda: ops.gemm(n, w, bias=bias, rowadd=tab, rows_per_group=rpg, act=act, out=o))
-            t_f = timeit(lambda: ops.gemm_ln(x, wf, sc, rowadd=tab, rows_per_group=rpg, act=act, out=o)) if not geglu else float("nan")
-            t_s = timeit(lambda: ops.gemm_ln(x, wf, sc, rowadd=tab, rows_per_group=rpg, act=act, out=o, stats=st))
-            tag = f"ln+gemm {M}x{N}x{K}{' geglu' if geglu else ''}{' +rowadd' if ra else ''}"
-            print(f"{tag:40s} layernorm {t_ln:6.3f} + gemm {t_g:6.3f} = {t_ln + t_g:6.3f} ms | fused, own statistics {t_f:6.3f} | fused, supplied statistics {t_s:6.3f} ms")
-        for M, res, ra in [(294912, True, False), (294912, True, True), (147456, True, False), (294912, False, False)]:
-            a, w, bias = rnd(M, 320), rnd(320, 320, scale=320 ** -0.5), rnd(320)
-            r = rnd(M, 320) if res else None
-            tab = rnd(32, 320) if ra else None
-            o = torch.empty((M, 320), device=dev, dtype=torch.float16)
-            st = ops.new_row_stats(M, dev)
-            t0 = timeit(lambda: ops.gemm(a, w, bias=bias, residual=r, rowadd=tab, rows_per_group=M // 32, out=o))
-            t1 = timeit(lambda: ops.gemm(a, w, bias=bias, residual=r, rowadd=tab, rows_per_group=M // 32, out=o, stats_out=st))
-            print(f"{'gemm ' + str(M) + 'x320x320' + (' +res' if res else '') + (' +rowadd' if ra else ''):40s} plain {t0:6.3f} ms | + row statistics {t1:6.3f} ms")
+            t_g = timeit(lambda: ops.gemm(n, w, rowadd=tab, rows_per_group=rpg, out=o))
+            t_f = timeit(lambda: ops.gemm_ln(x, wf, sc, rowadd=tab, rows_per_group=rpg, out=o))
+            tag = f"ln+gemm {M}x{N}x{K}{' +rowadd' if ra else ''}"
+            print(f"{tag:40s} layernorm {t_ln:6.3f} + gemm {t_g:6.3f} = {t_ln + t_g:6.3f} ms | fused {t_f:6.3f} ms")
         for B, HW, C in [(32, 9216, 320)]:
             x, w, g, b, bias = rnd(B, HW, C), rnd(C, C, scale=C ** -0.5), rnd(C), rnd(C), rnd(C)
             o = torch.empty((B * HW, C), device=dev, dtype=torch.float16)
-            st = ops.new_row_stats(B * HW, dev)
             t_n = timeit(lambda: ops.groupnorm(x, g, b, 32, 1e-6))
             n = ops.groupnorm(x, g, b, 32, 1e-6)
             t_g = timeit(lambda: ops.gemm(n.view(-1, C), w, bias=bias, out=o))
             t_t = timeit(lambda: ops.groupnorm_table(x, g, b, 32, 1e-6))
             tb = ops.groupnorm_table(x, g, b, 32, 1e-6)
             t_a = timeit(lambda: ops.gemm_affine(x, tb, w, bias=bias, out=o))
-            t_as = timeit(lambda: ops.gemm_affine(x, tb, w, bias=bias, out=o, stats_out=st))
-            print(f"{'gn+gemm ' + str(B) + 'x' + str(HW) + 'x' + str(C):40s} groupnorm {t_n:6.3f} + gemm {t_g:6.3f} = {t_n + t_g:6.3f} ms | table {t_t:6.3f} + affine gemm {t_a:6.3f} = "
-                  f"{t_t + t_a:6.3f} ms | affine gemm + row statistics {t_as:6.3f}")
+            print(f"{'gn+gemm ' + str(B) + 'x' + str(HW) + 'x' + str(C):40s} groupnorm {t_n:6.3f} + gemm {t_g:6.3f} = {t_n + t_g:6.3f} ms | table {t_t:6.3f} + affine gemm {t_a:6.3f} = {t_t + t_a:6.3f} ms")
     if "tgemm" in which:       # transposed-output projections (V^T for the attention kernels)
         for M, N, K in [(294912, 320, 320), (73728, 640, 640), (18432, 1280, 1280), (4608, 1280, 1280), (147456, 320, 320)]:
             a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
