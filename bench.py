@@ -358,6 +358,23 @@ def vae_ms_per_clip(dev, size, frames, batch=8):
     return sorted(times)[1]                                              # median of three
 
 
+def cpu_quota(root="/sys/fs/cgroup"):
+    """(raw text, CPUs) of the container's CPU bandwidth limit: cgroup v2 `cpu.max` ("<quota> <period>" or "max <period>") or cgroup v1
+    `cpu/cpu.cfs_quota_us` + `cpu.cfs_period_us` (-1 = none).  CPUs is None when there is no limit (or no cgroup file)."""
+    try:
+        raw = open(os.path.join(root, "cpu.max")).read().strip()
+        q, per = raw.split()[:2]
+        return raw, (None if q == "max" else int(q) / int(per))
+    except (OSError, ValueError):
+        pass
+    try:
+        raw = open(os.path.join(root, "cpu", "cpu.cfs_quota_us")).read().strip()
+        per = int(open(os.path.join(root, "cpu", "cpu.cfs_period_us")).read())
+        return raw, (int(raw) / per if int(raw) > 0 else None)
+    except (OSError, ValueError):
+        return None, None
+
+
 def cpu_baseline(ref_sd, den_sd, args, ctx):
     """The CPU oracle (a port of the reference's PyTorch path: the same ATen ops, fp32) on this host's cores, on a bounded
     sample, after one untimed warm-up pass (thread pool, allocator, oneDNN primitive caches):
@@ -415,11 +432,15 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
             O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
             sweep2[best] = time.perf_counter() - t0
         dt2 = sweep2[best]
-        # (3) ALL usable cores: one ATen call does not scale past `best` intra-op threads at this size (the sweep above), independent
-        # frames do -- P = usable // best workers (Python threads of this process: every thread owns its own OpenMP team of `best`
-        # threads, the GIL is released inside ATen, the weights are shared), each running the SAME frame-step on its own frame.
-        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else avail
-        P = max(1, min(usable, avail) // best)
+        # (3) ALL usable cores.  "Usable" = min(CPU affinity, cgroup CPU quota): on the GPU boxes of this pool the host has 128 cores / 256
+        # hardware threads and the container a quota of 16 CPUs (cpu.max "1600000 100000"), which is why 16 intra-op threads are best and
+        # every further thread only adds throttling.  When the quota leaves room for more than one `best`-thread worker, P = usable // best
+        # independent frames run at once (P Python threads of this process: every thread owns its own OpenMP team, the GIL is released
+        # inside ATen, the weights are shared) and `value` is the better of the two legs.
+        affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else avail
+        quota_raw, quota_cpus = cpu_quota()
+        usable = min(affinity, avail, int(quota_cpus + 0.5)) if quota_cpus else min(affinity, avail)
+        P = max(1, usable // best)
         frames_in = [synth_inputs(f, h, w, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100 + i) for i in range(P)]
 
         def worker(i):
@@ -435,25 +456,25 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
                 list(ex.map(worker, range(P)))
             dt3 = time.perf_counter() - t0
         torch.set_num_threads(avail)
-    quota = None
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            quota = open(path).read().strip()
-            break
-        except OSError:
-            pass
     single = f / (dt2 * args.ddim_steps)
     allcore = P * f / (dt3 * args.ddim_steps) if dt3 else single
     eff = (dt2 / dt3) if dt3 else 1.0                                     # 1.0 = P workers finish in the time of one
     use_all = allcore > single
     top = max(sweep2)
-    verdict = "more intra-op threads are slower for ONE call" if sweep2[top] > 1.05 * sweep2[best] and top > best else "ONE call by thread count"
-    why = (f"{verdict} ({', '.join(f'{k}: {v:.1f} s' for k, v in sorted(sweep2.items()))}) while {P} "
-           f"independent workers x {best} threads finish in {dt3:.1f} s ({100 * eff:.0f} % of linear): the cores are usable (affinity {usable}, "
-           f"cgroup cpu.max '{quota}'), ATen's per-operator fork/join over 1-2 images does not spread further") if dt3 else \
-          f"single worker only (affinity {usable}, {avail} intra-op threads)"
+    slower = sweep2[top] > 1.05 * sweep2[best] and top > best
+    sweep_txt = ", ".join(f"{k}: {v:.1f} s" for k, v in sorted(sweep2.items()))
+    if quota_cpus and quota_cpus < min(affinity, avail):
+        why = (f"the container's CPU quota is {quota_cpus:g} CPUs (cgroup cpu.max '{quota_raw}') on a host with {physical} physical cores / {affinity} hardware "
+               f"threads in the affinity mask: ONE call by thread count {sweep_txt} -- threads beyond the quota are throttled, so {best} threads ARE all usable cores")
+    elif dt3:
+        why = (f"{'more intra-op threads are slower for ONE call' if slower else 'ONE call by thread count'} ({sweep_txt}) while {P} independent workers x {best} "
+               f"threads finish in {dt3:.1f} s ({100 * eff:.0f} % of linear); no CPU quota (cgroup '{quota_raw}', affinity {affinity}): ATen's per-operator "
+               f"fork/join over 1-2 images does not spread further, independent frames do")
+    else:
+        why = f"single worker (affinity {affinity}, cgroup '{quota_raw}', {avail} intra-op threads; ONE call by thread count {sweep_txt})"
+    quota = quota_raw
     return {"value": allcore if use_all else single, "unit": "frames/s", "cores": P * best if use_all else best, "physical_cores": physical,
-            "usable_cores": usable, "cgroup_cpu_max": quota, "kind": "port",
+            "usable_cores": usable, "affinity": affinity, "cgroup_cpu_max": quota, "cgroup_quota_cpus": quota_cpus, "kind": "port",
             "single_process": {"frames_per_s": single, "threads": best, "s_per_frame_step": round(dt2, 2)},
             "all_cores": {"workers": P, "threads_per_worker": best, "s_for_all_workers": round(dt3, 2) if dt3 else None,
                           "frames_per_s": allcore, "parallel_efficiency": round(eff, 3)},
@@ -464,9 +485,9 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
                       f"intra-op threads (best of the sweep) = {dt1:.1f} s; (2) 1 DDIM step of {f} frame at {args.size}x{args.size} (reference_unet + "
                       f"denoising_unet, CFG pair, fp32, full-width random-init weights, literal algorithm) timed on "
                       f"{'/'.join(str(k) for k in sorted(sweep2))} threads, best = {best} threads = {dt2:.1f} s; (3) the same frame-step on "
-                      f"{P} independent frames at once, {best} threads each = {P * best} of {usable} usable cores; value = "
+                      f"{P} independent frame(s) at once, {best} threads each = {P * best} of {usable} usable cores; value = "
                       f"{'(3)' if use_all else '(2)'}: frames / ({args.ddim_steps} steps x wall time), one frame-step extrapolated linearly over "
-                      f"frames and steps.  Why not one {avail}-thread call: {why}"}
+                      f"frames and steps.  Cores: {why}"}
 
 
 if __name__ == "__main__":

@@ -133,3 +133,21 @@ def test_eight_rank_launch_protocol_under_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["clips_gathered"] == 8 and d["config"]["parallelism"] == "dp8"
     assert len(set(d["clip_means"])) == 8                               # eight different clips (seeds 100 .. 107) came back
+
+
+def test_cpu_quota_parsing(tmp_path):
+    """bench.py's cpu_baseline reports min(affinity, cgroup CPU quota) as the usable cores: the GPU boxes of this pool run the container with
+    cpu.max = "1600000 100000" (16 CPUs) on a 128-core host, which is the whole story behind "more than 16 threads are slower"."""
+    sys.path.insert(0, ROOT)
+    import bench
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert bench.cpu_quota(str(tmp_path)) == ("1600000 100000", 16.0)
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cpu_quota(str(tmp_path)) == ("max 100000", None)
+    v1 = tmp_path / "v1" / "cpu"
+    v1.mkdir(parents=True)
+    (v1 / "cpu.cfs_quota_us").write_text("-1\n"); (v1 / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cpu_quota(str(tmp_path / "v1")) == ("-1", None)
+    (v1 / "cpu.cfs_quota_us").write_text("800000\n")
+    assert bench.cpu_quota(str(tmp_path / "v1")) == ("800000", 8.0)
+    assert bench.cpu_quota(str(tmp_path / "nowhere")) == (None, None)
