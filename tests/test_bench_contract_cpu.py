@@ -151,3 +151,24 @@ def test_cpu_quota_parsing(tmp_path):
     (v1 / "cpu.cfs_quota_us").write_text("800000\n")
     assert bench.cpu_quota(str(tmp_path / "v1")) == ("800000", 8.0)
     assert bench.cpu_quota(str(tmp_path / "nowhere")) == (None, None)
+
+
+def test_round5_line_reports_the_usable_cores_of_its_cpu_baseline():
+    d = _record("r05_bench.json")
+    assert "768x768" in d["metric"] and "configs[1]" in d["config"]["workload"] and d["n_gpus"] == d["n_ranks_seen"] == 1
+    frames = int(re.search(r"(\d+)f,", d["metric"]).group(1))
+    assert math.isclose(d["value"], frames / (d["ms_per_step"] * 1e-3), rel_tol=1e-6) and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-9) and 0.25 < r["frac"] < 1.0
+    assert "measured" in r["traffic_source"] and r["traffic"] >= r["algorithmic_bytes"]
+    c = d["cpu_baseline"]
+    # cores = ALL usable cores = min(affinity, cgroup CPU quota); the line carries the evidence (affinity, quota, thread sweep) and says so
+    assert c["kind"] == "port" and c["cores"] == c["usable_cores"] == min(c["affinity"], int(c["cgroup_quota_cpus"])) and c["value"] < d["value"]
+    sweep = {int(k): v for k, v in c["thread_sweep_s_per_step_at_size"].items()}
+    assert min(sweep, key=sweep.get) == c["single_process"]["threads"] and len(sweep) >= 3
+    assert "quota" in c["sample"] and "extrapolated" in c["sample"] and str(c["cgroup_cpu_max"]) in c["sample"]
+    assert math.isclose(c["value"], 1.0 / (c["single_process"]["s_per_frame_step"] * 20), rel_tol=2e-2)
+    # the fused normalisations of round 5 are on the line: LayerNorm folded into q|k|v, GroupNorm inside proj_in
+    labels = " ".join(s["label"] for s in d["top_launch_shapes"])
+    assert " ln" in labels and d["kernel_families"]["layernorm"]["ms_per_clip"] < 80 and d["kernel_families"]["groupnorm"]["ms_per_clip"] < 105
+    assert 0.0 < d["mfma_frac_whole_loop"] < 1.0 and d["e2e_frames_per_s"] < d["value"] and d["vae_ms_per_clip"] < 310
