@@ -65,16 +65,15 @@ struct WsParams {
 };
 
 // Prologues.  Both rest on the fact that a stage of this kernel holds WHOLE rows of A (all of K) in LDS before the matrix core reads it.
-//   PRO_LNF  LayerNorm folded into the Linear that consumes it (norm2 -> attn2.to_q, norm3 / ff_norm -> ff.net.0, the motion module's
-//            norms -> q|k|v: reference src/models/attention.py:131-157,339-364, src/models/motion_module.py:229-272).  With
+//   PRO_LNF  LayerNorm folded into the Linear that consumes it (norm2 -> attn2.to_q, the motion module's norms -> q|k|v: reference
+//            src/models/attention.py:131-141,339-347, src/models/motion_module.py:245-268).  With
 //            W'[n][k] = fp16(gamma[k] W[n][k]),  s[n] = sum_k W'[n][k],  c[n] = sum_k beta[k] W[n][k] + bias[n]:
 //                LN(x) . W^T + bias = rstd * (x . W'^T - mu * s) + c
 //            so the GEMM runs on the RAW rows and the normalised tensor is never written or read (4 bytes per element and a launch
 //            saved per LayerNorm).  The loader waves, which own eight rows of every tile they have just DMA'd, compute the exact two-pass
-//            (mu, rstd) of their rows from the landed stage and leave a = rstd, b = -mu * rstd in a small LDS ring; the epilogue applies
-//            a * acc + (b * s + c) -- in the store waves for the plain flavours, in the COMPUTE waves for GEGLU (whose memory waves are
-//            bound by the GELU arithmetic and now skip the bias add).  s is summed from the ROUNDED W', so x . W'^T - mu * s is exactly
-//            sum_k (x_k - mu) W'[n][k]: the fold is as insensitive to the row mean as the two-pass LayerNorm it replaces.
+//            (mu, rstd) of their rows from the landed stage (sum on v_dot2, 8-lane reductions on DPP) and leave a = rstd, b = -mu * rstd
+//            in a small LDS ring; the store waves apply a * acc + (b * s + c).  s is summed from the ROUNDED W', so x . W'^T - mu * s is
+//            exactly sum_k (x_k - mu) W'[n][k]: the fold is as insensitive to the row mean as the two-pass LayerNorm it replaces.
 //   PRO_AFF  per-(image, channel) affine x * scale + shift applied to the landed stage IN PLACE, one rounding to fp16 -- GroupNorm's
 //            apply sweep in front of proj_in (reference src/models/transformer_3d.py:60-68,121-137, src/models/motion_module.py:121-124,
 //            159-170) with scale = rstd * gamma, shift = beta - mean * scale from md_groupnorm_table_f16: bit-identical to
@@ -119,8 +118,8 @@ struct WsCfg {
 };
 
 // Sum over the 8 adjacent lanes that share a row (lane ^ 1, lane ^ 2, then the mirrored half-row = lane ^ 4 once the quads are uniform), on
-// the DPP path: three VALU operations, every lane gets the total.  The __shfl_xor form (ds_bpermute through the LDS pipe) put two chains
-// of three dependent ~100-cycle exchanges into every tile of the store waves: +30 % on the producers (0.106 -> 0.138 ms at M = 294912).
+// the DPP path: three VALU operations, every lane gets the total (the __shfl_xor form goes through ds_bpermute: two chains of three
+// dependent ~100-cycle LDS exchanges per tile).
 __device__ __forceinline__ float ws_sum8(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
@@ -283,18 +282,14 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     const int prow = lw * 8 + (lane >> 3), psub = lane & 7;
     const int pswz = ws_swz<CPR>(prow);
     auto ln_stats = [&](const char* st, int lslot) {            // exact two-pass (mu, rstd) of the landed row -> (a, b) = (rstd, -mu rstd)
-      float v[PJ][8];
+      half8_t h[PJ];
 #pragma unroll
-      for (int j = 0; j < PJ; ++j) {
-        const half8_t h = *reinterpret_cast<const half8_t*>(st + (prow * CPR + ((8 * j + psub) ^ pswz)) * 16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[j][e] = (float)h[e];
-      }
-      float sum = 0.f;
+      for (int j = 0; j < PJ; ++j) h[j] = *reinterpret_cast<const half8_t*>(st + (prow * CPR + ((8 * j + psub) ^ pswz)) * 16);
+      float sum = 0.f;                                          // v_dot2_f32_f16 against (1, 1): two elements per instruction, fp32 accumulate
 #pragma unroll
       for (int j = 0; j < PJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum += v[j][e];
+        for (int e = 0; e < 8; e += 2) sum = __builtin_amdgcn_fdot2(half2_t{h[j][e], h[j][e + 1]}, half2_t{(half_t)1.0f, (half_t)1.0f}, sum, false);
       sum = ws_sum8(sum);
       const float mu = sum * (1.0f / K);
       float sq = 0.f;
@@ -302,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       for (int j = 0; j < PJ; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float d = v[j][e] - mu;
+          const float d = (float)h[j][e] - mu;
           sq += d * d;
         }
       sq = ws_sum8(sq);
