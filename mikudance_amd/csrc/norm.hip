@@ -83,6 +83,30 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
   }
 }
 
+// Sum of the (sum, sum of squares) partials pp[k * stride], k = k0, k0 + step, ... < n, IN THAT ORDER (every caller that must agree bit for
+// bit -- gn_apply_kernel, gn_table_kernel -- walks the same sequence), with eight loads in flight: the plain loop compiles to one L2
+// round trip per partial (s_waitcnt vmcnt(0) inside the loop), i.e. 24-72 serial latencies in front of every workgroup's sweep.
+__device__ __forceinline__ void gn_sum_partials(const float* __restrict__ pp, size_t stride, int k0, int step, int n, float& a, float& c2) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  int k = k0;
+#ifndef GN_SERIAL_PARTIALS                     // A/B knob: the one-load-per-iteration form of rounds 1-4
+  for (; k + 7 * step < n; k += 8 * step) {
+    f2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f2*>(pp + (size_t)(k + u * step) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a += v[u].x;
+      c2 += v[u].y;
+    }
+  }
+#endif
+  for (; k < n; k += step) {
+    a += pp[(size_t)k * stride];
+    c2 += pp[(size_t)k * stride + 1];
+  }
+}
+
 // Images of many slabs (the AutoencoderKL at 768 x 768: 576 slabs per image; the temporal decoder's clip-wide GroupNorm: ~9000): every
 // workgroup of the apply sweep re-reducing all partial sums of its image is O(slabs) work per workgroup and O(slabs^2) per image -- 290 of
 // the 421 ms of a temporal-decoder chunk in round 4's form (profiles/r05_vae_temporal.json).  Above GN_FIN_SLABS slabs ONE small launch
@@ -96,10 +120,7 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, const float* 
   if (g >= G) return;
   float a = 0.f, c2 = 0.f;
   const float* pp = part + ((size_t)b * nslab * G + g) * 2;
-  for (int k = j; k < nslab; k += 8) {
-    a += pp[(size_t)k * G * 2];
-    c2 += pp[(size_t)k * G * 2 + 1];
-  }
+  gn_sum_partials(pp, (size_t)G * 2, j, 8, nslab, a, c2);
 #pragma unroll
   for (int o = 1; o < 8; o <<= 1) {
     a += __shfl_xor(a, o, 64);
@@ -130,11 +151,7 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
       continue;
     }
     float a = 0.f, c2 = 0.f;
-    const float* pp = part + ((size_t)b * nslab * G + g) * 2;
-    for (int k = 0; k < nslab; ++k) {
-      a += pp[(size_t)k * G * 2];
-      c2 += pp[(size_t)k * G * 2 + 1];
-    }
+    gn_sum_partials(part + ((size_t)b * nslab * G + g) * 2, (size_t)G * 2, 0, 1, nslab, a, c2);
     const float n = (float)HW * (float)cpg;
     const float mu = a / n;                               // mean of x - k
     const float var = fmaxf(c2 / n - mu * mu, 0.f);
@@ -343,11 +360,7 @@ __global__ void gn_table_kernel(const float* __restrict__ part, const float* __r
       rstd = fin[((size_t)b * G + g) * 2 + 1];
     } else {
       float a = 0.f, c2 = 0.f;
-      const float* pp = part + ((size_t)b * nslab * G + g) * 2;
-      for (int k = 0; k < nslab; ++k) {
-        a += pp[(size_t)k * G * 2];
-        c2 += pp[(size_t)k * G * 2 + 1];
-      }
+      gn_sum_partials(part + ((size_t)b * nslab * G + g) * 2, (size_t)G * 2, 0, 1, nslab, a, c2);
       const float n = (float)HW * (float)cpg;
       const float mu = a / n;                             // mean of x - k
       mean = pilot[(size_t)b * G + g] + mu;
