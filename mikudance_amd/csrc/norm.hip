@@ -67,13 +67,34 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict_
     sq[r * C + cc * 8 + e] = q[e];
   }
   __syncthreads();
+#ifndef GN_STATS_SERIAL_TAIL
+  // two short steps instead of G threads walking R * cpg LDS words each (120-960 dependent reads at the END of every workgroup, with 32 of
+  // its ~500 threads active): one thread per channel sums its R row lanes into row 0, then one thread per group sums its cpg channels
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = ss[c], c2 = sq[c];
+    for (int rr = 1; rr < R; ++rr) {
+      a += ss[rr * C + c];
+      c2 += sq[rr * C + c];
+    }
+    ss[c] = a;                                  // row 0 of column c is read and written by this thread only
+    sq[c] = c2;
+  }
+  __syncthreads();
+#endif
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     float a = 0.f, c2 = 0.f;
+#ifndef GN_STATS_SERIAL_TAIL
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      a += ss[c];
+      c2 += sq[c];
+    }
+#else
     for (int rr = 0; rr < R; ++rr)
       for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
         a += ss[rr * C + c];
         c2 += sq[rr * C + c];
       }
+#endif
     float* o = part + (((size_t)b * nslab + sl) * G + g) * 2;
     o[0] = a;
     o[1] = c2;
