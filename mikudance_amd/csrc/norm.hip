@@ -165,6 +165,25 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
   // are re-read first
   const int b = zigzag ? gridDim.y - 1 - blockIdx.y : blockIdx.y, sl = zigzag ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const int cpg = C / G;
+  const int p0 = sl * slab, p1 = min(p0 + slab, HW);
+  const size_t base = (size_t)b * HW * C + cc * 8, xbase = (size_t)b * HW * ldx + cc * 8;
+  // The first rows of this thread and its gamma / beta are requested BEFORE the statistics are assembled: none of them depends on
+  // the partial sums, and every workgroup of a launch would otherwise sit through the partials' L2 round trips with nothing in flight
+  // (all workgroups start together: that latency was dead time at the head of every apply launch).  In place (y == x) is unaffected:
+  // an element is read and written by the same thread.
+#ifndef GN_NO_PREFETCH
+  constexpr int PRE = GN_UNROLL;
+#else
+  constexpr int PRE = 0;
+#endif
+  half8_t pre[PRE > 0 ? PRE : 1];
+#pragma unroll
+  for (int u = 0; u < PRE; ++u) {
+    const int p = p0 + r + u * R;
+    pre[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    if (p < p1) pre[u] = *reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx);
+  }
+  const half8_t gm = *reinterpret_cast<const half8_t*>(gamma + cc * 8), bt = *reinterpret_cast<const half8_t*>(beta + cc * 8);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     if (fin) {                                            // many slabs: reduced once by gn_finalize_kernel
       mean_s[g] = fin[((size_t)b * G + g) * 2];
@@ -185,14 +204,10 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
   for (int e = 0; e < 8; ++e) {
     const int c = cc * 8 + e;
     const int g = c / cpg;
-    sc[e] = rstd_s[g] * (float)gamma[c];
-    sf[e] = __builtin_fmaf(-mean_s[g], sc[e], (float)beta[c]);        // explicit fma here, in gn_table_kernel and in the in-LDS apply of
+    sc[e] = rstd_s[g] * (float)gm[e];
+    sf[e] = __builtin_fmaf(-mean_s[g], sc[e], (float)bt[e]);          // explicit fma here, in gn_table_kernel and in the in-LDS apply of
   }                                                                    // wsgemm_kernel<PRO_AFF>: the three must agree bit for bit
-  const int p0 = sl * slab, p1 = min(p0 + slab, HW);
-  const size_t base = (size_t)b * HW * C + cc * 8, xbase = (size_t)b * HW * ldx + cc * 8;
-#pragma unroll GN_UNROLL
-  for (int p = p0 + r; p < p1; p += R) {
-    const half8_t v = *reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx);
+  auto finish = [&](const half8_t& v, int p) {
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -201,7 +216,14 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
       o[e] = (half_t)f;
     }
     norm_store(reinterpret_cast<half8_t*>(y + base + (size_t)p * C), o);
+  };
+#pragma unroll
+  for (int u = 0; u < PRE; ++u) {
+    const int p = p0 + r + u * R;
+    if (p < p1) finish(pre[u], p);
   }
+#pragma unroll GN_UNROLL
+  for (int p = p0 + r + PRE * R; p < p1; p += R) finish(*reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx), p);
 }
 
 // ------------------------------------------------------------------------------------------------ GroupNorm, small images: ONE sweep
@@ -325,6 +347,7 @@ extern "C" int md_groupnorm_ld_nhwc_f16(const void* x, int ldx, void* y, const v
   MD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ldx == C || x != y),
                "md_groupnorm: ldx=%d must be a multiple of 8 and >= C=%d, x 16-byte aligned; in place only with ldx == C", ldx, C);
   MD_CHECK_ARG(C / 8 <= 1024, "md_groupnorm: C=%d too large", C);
+  MD_CHECK_ARG(((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0, "md_groupnorm: gamma / beta must be 16-byte aligned");
   MD_CHECK_ARG(ws_bytes >= md_groupnorm_workspace_bytes(B, HW, C, G), "md_groupnorm: workspace too small");
   {
     int Rs, NTs;
