@@ -167,22 +167,8 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
   const int cpg = C / G;
   const int p0 = sl * slab, p1 = min(p0 + slab, HW);
   const size_t base = (size_t)b * HW * C + cc * 8, xbase = (size_t)b * HW * ldx + cc * 8;
-  // The first rows of this thread and its gamma / beta are requested BEFORE the statistics are assembled: none of them depends on
-  // the partial sums, and every workgroup of a launch would otherwise sit through the partials' L2 round trips with nothing in flight
-  // (all workgroups start together: that latency was dead time at the head of every apply launch).  In place (y == x) is unaffected:
-  // an element is read and written by the same thread.
-#ifndef GN_NO_PREFETCH
-  constexpr int PRE = GN_UNROLL;
-#else
-  constexpr int PRE = 0;
-#endif
-  half8_t pre[PRE > 0 ? PRE : 1];
-#pragma unroll
-  for (int u = 0; u < PRE; ++u) {
-    const int p = p0 + r + u * R;
-    pre[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    if (p < p1) pre[u] = *reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx);
-  }
+  // (Requesting the thread's first rows before the statistics are assembled was measured in round 5 and is neutral -- GroupNorm family
+  // 90.0 vs 89.8-90.2 ms per clip, profiles/r05_ab_groupnorm_apply_prefetch.log: the other workgroups of the CU cover that latency.)
   const half8_t gm = *reinterpret_cast<const half8_t*>(gamma + cc * 8), bt = *reinterpret_cast<const half8_t*>(beta + cc * 8);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     if (fin) {                                            // many slabs: reduced once by gn_finalize_kernel
@@ -217,13 +203,8 @@ __global__ void gn_apply_kernel(const half_t* x, half_t* y, const float* __restr
     }
     norm_store(reinterpret_cast<half8_t*>(y + base + (size_t)p * C), o);
   };
-#pragma unroll
-  for (int u = 0; u < PRE; ++u) {
-    const int p = p0 + r + u * R;
-    if (p < p1) finish(pre[u], p);
-  }
 #pragma unroll GN_UNROLL
-  for (int p = p0 + r + PRE * R; p < p1; p += R) finish(*reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx), p);
+  for (int p = p0 + r; p < p1; p += R) finish(*reinterpret_cast<const half8_t*>(x + xbase + (size_t)p * ldx), p);
 }
 
 // ------------------------------------------------------------------------------------------------ GroupNorm, small images: ONE sweep
