@@ -149,3 +149,58 @@ def test_temporal_pitch_two_mod_four_would_be_conflict_free():
     good = [P for P in range(16) if conflict_free_b128(lambda lane, P=P: (lane & 15) * (P + 32) * 16 + (lane >> 4) * 16)]
     assert good == [2, 6, 10, 14]
     assert conflict_ways_b128(lambda lane: (lane & 15) * 41 * 16 + (lane >> 4) * 16) == 2      # today's pitch
+
+
+# ------------------------------------------------------------------------------------------------ streaming GEMM: prologue flavours (round 5)
+def ws_swz(cpr, row):
+    return (row >> 1) & 7 if cpr == 40 else row & 15               # gemm_ws.h: ws_swz<CPR>
+
+
+@pytest.mark.parametrize("K", [320, 640])
+def test_wsgemm_prologue_lanes_touch_exactly_the_rows_their_wave_loaded(K):
+    """PRO_LNF / PRO_AFF (csrc/gemm_ws.h): a loader wave works on a landed stage after ITS OWN counted vmcnt wait only, so every 16-byte
+    slot its lanes read or rewrite must have been written by a DMA instruction of the same wave; the lane map (row = 8 lw + lane / 8, chunks
+    8 j + lane % 8) composed with the stage swizzle must cover each of the wave's slots exactly once (an in-place rewrite that skipped or
+    doubled a slot would corrupt the tile), and chunk c of a row must be the global chunk the DMA put there."""
+    cpr, tr = K // 8, 16
+    stage_slots = tr * cpr
+    dpt = stage_slots * 16 // 1024                                  # DMA wave-instructions per tile (1 KiB each)
+    per = dpt // 2
+    assert per * 64 == 8 * cpr                                       # static_assert of the kernel: a loader wave owns whole rows
+    pj = cpr // 8
+    # DMA: piece pidx = (lw * PER + i) * 64 + lane is LDS slot pidx (lane linear) <- global chunk (c ^ swz(r)) of row r = pidx / CPR
+    holds, writer = {}, {}
+    for lw in range(2):
+        for i in range(per):
+            for lane in range(64):
+                pidx = (lw * per + i) * 64 + lane
+                r, c = divmod(pidx, cpr)
+                holds[pidx] = (r, c ^ ws_swz(cpr, r))
+                writer[pidx] = lw
+    assert sorted(holds.values()) == [(r, c) for r in range(tr) for c in range(cpr)]     # a permutation of the tile
+    for lw in range(2):
+        touched = []
+        for lane in range(64):
+            prow, psub = lw * 8 + (lane >> 3), lane & 7
+            for j in range(pj):
+                logical = 8 * j + psub                               # the chunk whose gamma / beta / table entries the lane keeps in registers
+                slot = prow * cpr + (logical ^ ws_swz(cpr, prow))
+                assert writer[slot] == lw, "a prologue lane would read a slot another wave's DMA wrote"
+                assert holds[slot] == (prow, logical), "the slot does not hold the chunk the lane thinks it holds"
+                touched.append(slot)
+        assert sorted(touched) == list(range(lw * per * 64, (lw + 1) * per * 64))        # each of the wave's slots exactly once
+
+
+def test_wsgemm_contiguous_row_blocks_cover_every_tile_once():
+    """PRO_AFF streams walk contiguous row blocks (tile0 = stream * tps, tstep = 1): every tile of the matrix belongs to exactly one stream,
+    whatever the remainder, and a stream of the benchmark shape stays inside one image (its table is loaded once)."""
+    for M, streams, rows_per_image in [(294912, 256, 9216), (32768 + 16 * 7, 256, 2048), (36864, 256, 1024), (73728, 128, 9216)]:
+        ntiles = (M + 15) // 16
+        tps = (ntiles + streams - 1) // streams
+        seen = []
+        for s in range(streams):
+            tile0 = s * tps
+            seen += list(range(tile0, tile0 + max(0, min(tps, ntiles - tile0))))
+        assert seen == list(range(ntiles))
+        if M == 294912:
+            assert all((s * tps * 16) // rows_per_image == ((s * tps + tps - 1) * 16) // rows_per_image for s in range(streams))
