@@ -51,6 +51,7 @@ struct GemmParams {
   int kw;                 // conv: filter taps along x, 3 (3 x 3) or 1 (3 x 1: the centre column only; K = 3 Cin)
   int tiles_n, tiles_total;
   int tiles_m, group_m;   // gemm_sp_kernel: tile order (group_m row panels of tiles are walked column by column)
+  int reverse;            // gemm_sp_kernel: walk the tile order BACKWARDS (an A operand larger than the memory-side cache, written front to back by the previous kernel)
 };
 
 __device__ __attribute__((aligned(64))) half_t g_zero_page[32] = {};

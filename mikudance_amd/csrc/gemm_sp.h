@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     // the order, its 32 CUs 32 consecutive positions at a time (gridDim.x % 8 == 0 or gridDim.x == nwg)
     const int v = (int)blockIdx.x + i * (int)gridDim.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = v & 7, idx = v >> 3;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.reverse) t = nwg - 1 - t;
     // tile order: groups of group_m row panels, walked column by column inside a group, so that the tiles the CUs of one XCD work
     // on at the same time form a (group_m x 32 / group_m) block: they share group_m A panels AND 32 / group_m W panels through
     // that XCD's L2.  Row-major order (group_m = 1) makes the 32 CUs stream 32 different W panels: the wide-N GEMMs then run at
@@ -562,6 +563,10 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_total = p.tiles_m * p.tiles_n;
   p.group_m = group_m;
+  // An A operand larger than the 256-MiB memory-side cache that the previous kernel wrote front to back (FeedForward's hidden tensor:
+  // 755 MB at the 96 x 96 level) is walked BACKWARDS: its tail is the part still cached.  MD_SP_REVERSE = 0 switches it off (A/B).
+  static const int rev = md_env_int("MD_SP_REVERSE", 1);
+  p.reverse = !CONV && !GEGLU && rev && !p.bias_rows && (size_t)p.M * (size_t)p.lda * 2 > ((size_t)256 << 20);
   const int ncu = md_device_cus();
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
   hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);
