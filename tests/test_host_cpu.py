@@ -210,3 +210,27 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
     assert lib.md_conv3x3_plan(60, 128, 128, 960, 320, 1, 0, 4, ncu) == 135
     # a smaller chip changes the rounds, hence the tile: the model is per device
     assert lib.md_gemm_plan(18432, 1280, 1280, 0, 0, 5, 192) in (134, 135, 124)
+
+
+def test_fused_normalisation_plans_are_the_measured_table():
+    """md_gemm_ln_plan / md_gemm_affine_plan (no device touched): the fused normalisations exist exactly where they won their same-box A/B
+    (profiles/r05_ab_fused_norms*.log) -- K = 320, plain epilogue, N a multiple of 320, >= 32768 rows in whole 16-row tiles -- and nowhere
+    else; the host (blocks.ln_linear / gn_linear) runs the literal operator pair wherever a plan says no."""
+    from mikudance_amd import _lib
+    lib = _lib.load()
+    ACT_NONE, ACT_GEGLU = 0, 3
+    yes = [(294912, 960, 320, 2), (294912, 320, 320, 0), (147456, 320, 320, 0), (983040, 960, 320, 2), (32768, 640, 320, 0), (32784, 320, 320, 0)]
+    for M, N, K, epi in yes:
+        assert lib.md_gemm_ln_plan(M, N, K, ACT_NONE, epi) == 1, (M, N, K, epi)
+    no = [(294912, 2560, 320, ACT_GEGLU, 0),          # GEGLU: memory waves VALU bound (and the fold costs the consumer its warm input)
+          (73728, 1920, 640, ACT_NONE, 2), (73728, 640, 640, ACT_NONE, 0),    # K = 640: loader waves' work redone per column group
+          (18432, 1280, 1280, ACT_NONE, 0), (4608, 1280, 1280, ACT_NONE, 0),  # not streaming-kernel shapes
+          (16384, 320, 320, ACT_NONE, 0), (32776, 320, 320, ACT_NONE, 0),     # too few rows / not whole tiles
+          (294912, 320, 320, ACT_NONE, 1), (294912, 256, 320, ACT_NONE, 0), (294912, 2880, 320, ACT_NONE, 0)]   # residual; N not k x 320; > 8 groups
+    for M, N, K, act, epi in no:
+        assert lib.md_gemm_ln_plan(M, N, K, act, epi) == 0, (M, N, K, act, epi)
+    assert lib.md_gemm_affine_plan(294912, 320, 320, 9216) == 1 and lib.md_gemm_affine_plan(983040, 320, 320, 16384) == 1
+    assert lib.md_gemm_affine_plan(73728, 640, 320, 9216) == 1                      # two column groups
+    for M, N, K, rpi in [(73728, 640, 640, 2304), (294912, 320, 320, 9216 + 8), (294912, 320, 320, 9000), (294912, 320, 320, 0), (16384, 320, 320, 1024),
+                         (18432, 1280, 1280, 576)]:
+        assert lib.md_gemm_affine_plan(M, N, K, rpi) == 0, (M, N, K, rpi)
