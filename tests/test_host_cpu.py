@@ -234,3 +234,33 @@ def test_fused_normalisation_plans_are_the_measured_table():
     for M, N, K, rpi in [(73728, 640, 640, 2304), (294912, 320, 320, 9216 + 8), (294912, 320, 320, 9000), (294912, 320, 320, 0), (16384, 320, 320, 1024),
                          (18432, 1280, 1280, 576)]:
         assert lib.md_gemm_affine_plan(M, N, K, rpi) == 0, (M, N, K, rpi)
+
+
+def test_ln_fold_algebra_and_row_mean_insensitivity():
+    """packing.ln_fold: LN(x) @ W^T + bias == rstd * (x @ Wf^T - mu * s) + c.  With the fp16-rounded Wf the identity holds to the rounding
+    of gamma * W (2^-11 per weight); with s summed from the ROUNDED Wf the mean term cancels exactly, so shifting every row by 1000 sigma
+    changes nothing but fp64 noise -- and the GEGLU row interleave commutes with the fold."""
+    import torch
+    from mikudance_amd import packing
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 64, 96, 320
+    x = torch.randn(M, K, generator=g, dtype=torch.float64)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    bias = (torch.randn(N, generator=g) * 0.2).half()
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).half()
+    beta = (0.3 * torch.randn(K, generator=g)).half()
+    wf, sc = packing.ln_fold(w, bias, gamma, beta)
+    assert wf.dtype == torch.float16 and sc.dtype == torch.float32 and sc.shape == (2, N)
+    assert torch.equal(sc[0].double(), wf.double().sum(1).float().double())                      # s is the sum of the ROUNDED weights
+    def folded(xx):
+        mu = xx.mean(1, keepdim=True)
+        rstd = torch.rsqrt(((xx - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+        return rstd * (xx @ wf.double().t() - mu * wf.double().sum(1)) + sc[1].double()
+    ref = torch.nn.functional.layer_norm(x, (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + bias.double()
+    assert (folded(x) - ref).abs().max() < 2e-3 * ref.abs().max()                                # rounding of gamma * W to fp16
+    assert (folded(x + 1000.0) - folded(x)).abs().max() < 1e-7 * ref.abs().max()                 # (x - mu) . Wf: the mean never reaches the sum
+    wp2, bp2 = packing.geglu_weight(torch.cat([w, w[:32]]), torch.cat([bias, bias[:32]]), "cpu")
+    wf2, sc2 = packing.ln_fold(wp2, bp2, gamma, beta)
+    wf3, sc3 = packing.ln_fold(torch.cat([w, w[:32]]), torch.cat([bias, bias[:32]]), gamma, beta)
+    wp3, cp3 = packing.geglu_weight(wf3, sc3[1], "cpu")
+    assert torch.equal(wf2, wp3) and torch.allclose(sc2[1], cp3.float(), atol=1e-3)              # interleave(fold) == fold(interleave)
