@@ -75,8 +75,11 @@ def main():
 
 def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipeline, SCHED_KWARGS, build_models, synth_inputs):
     if world > 1:
-        # N ranks share the host: cap the intra-op pool (weight synthesis, packing) so that 8 ranks do not spin 8 x 128 threads
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+        # N ranks share the host: cap the intra-op pool (weight synthesis, packing) so that 8 ranks do not spin 8 x 128 threads -- and
+        # count the cores the container may actually use (the GPU boxes of this pool: a 16-CPU cgroup quota on a 128-core host)
+        quota = cpu_quota()[1]
+        usable = min(os.cpu_count() or world, int(quota + 0.5)) if quota else (os.cpu_count() or world)
+        torch.set_num_threads(max(1, usable // world))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dry = args.dry_run_cpu
     if dry:
