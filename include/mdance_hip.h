@@ -79,7 +79,10 @@ int md_conv_nhwc_f16(const void* X, int ldx, const void* W, void* Y, int ldy, in
 int md_softmax_rows_f16(void* x, int ldx, int rows, int cols, float scale, void* stream);
 
 /* GroupNorm(G, eps) [+SiLU] over (B, HW, C) NHWC.  src/models/resnet.py:20-28,220-221,231,237;
- * src/models/transformer_3d.py:60-62,130; src/models/motion_module.py:121-123,164; unet_3d_mix.py:591-592. */
+ * src/models/transformer_3d.py:60-62,130; src/models/motion_module.py:121-123,164; unet_3d_mix.py:591-592.
+ * Alignment (all md_groupnorm_* entries): x, y, gamma and beta must be 16-byte aligned and C % 8 == 0 (the apply sweep loads gamma /
+ * beta eight channels at a time); MD_ERR_ARG otherwise.  md_groupnorm_table_f16 reads gamma / beta as scalars but keeps the same rule
+ * so that a caller can switch between the fused and the literal pair without re-packing. */
 size_t md_groupnorm_workspace_bytes(int B, int HW, int C, int G);
 int md_groupnorm_nhwc_f16(const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int G,
                           float eps, int silu, void* workspace, size_t ws_bytes, void* stream);

@@ -192,7 +192,7 @@ def ln_linear(pk, h, norm, lin, bias=None, rowadd=None, rows_per_group=0, act=op
     """LayerNorm(pk[norm + 'w'], pk[norm + 'b']) -> Linear(pk[lin], pk[bias]) [+ row term] [GEGLU] on the token matrix h."""
     M, K = h.shape
     w = pk[lin]
-    if FUSE_NORMS and ops.gemm_ln_plan(M, w.shape[0], K, act, rowadd is not None):
+    if FUSE_NORMS and ops.gemm_ln_plan(M, w.shape[0], K, act, rowadd is not None, a=h):
         fk = lin + ":ln"
         if fk not in pk:                  # folded once per layer, on first use (only the layers the fused kernel serves pay for it)
             pk[fk] = packing.ln_fold(w, None if bias is None else pk[bias], pk[norm + "w"], pk[norm + "b"])
@@ -206,7 +206,7 @@ def gn_linear(x, gamma, beta, eps, w, bias):
     """GroupNorm(32, eps) (no SiLU) -> 1 x 1 conv / Linear on the tokens of x (B, H, W, C); returns [B*H*W, N]."""
     B, C = x.shape[0], x.shape[-1]
     M = x.numel() // C
-    if FUSE_NORMS and ops.gemm_affine_plan(M, w.shape[0], C, M // B):
+    if FUSE_NORMS and ops.gemm_affine_plan(M, w.shape[0], C, M // B, x=x):
         return ops.gemm_affine(x, ops.groupnorm_table(x, gamma, beta, GROUPS, eps), w, bias=bias)
     return ops.gemm(tokens(ops.groupnorm(x, gamma, beta, GROUPS, eps)), w, bias=bias)
 

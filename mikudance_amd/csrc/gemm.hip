@@ -570,7 +570,7 @@ static void launch_ws_tpr(const WsParams& p, hipStream_t stream) {
 template <int KS, int CB>
 static void launch_ws(const GemmParams& g, hipStream_t stream) {
   constexpr int GC = 64 * CB;
-  WsParams p;
+  WsParams p = {};
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = g.residual; p.rowadd = g.rowadd;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr; p.ldra = g.ldra; p.M = g.M; p.N = g.N; p.rows_per_group = g.rows_per_group;
   p.groups = g.N / GC;
@@ -591,7 +591,7 @@ static bool ws_geglu_eligible(const GemmParams& p) {
 }
 
 static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
-  WsParams p;
+  WsParams p = {};
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = nullptr; p.rowadd = nullptr;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = 0; p.ldra = 0; p.M = g.M; p.N = g.N; p.rows_per_group = 1;
   p.groups = g.N / 256;

@@ -563,10 +563,14 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_total = p.tiles_m * p.tiles_n;
   p.group_m = group_m;
-  // An A operand larger than the 256-MiB memory-side cache that the previous kernel wrote front to back (FeedForward's hidden tensor:
-  // 755 MB at the 96 x 96 level) is walked BACKWARDS: its tail is the part still cached.  MD_SP_REVERSE = 0 switches it off (A/B).
+  // FeedForward's output projection (K = 4 N: the only plain GEMM whose A -- the GEGLU hidden tensor, 755 MB at the 96 x 96 level -- is known
+  // to have just been written front to back by the previous kernel) walks A BACKWARDS when A exceeds the 256-MiB memory-side cache of
+  // the MI355X: its tail is the part still cached (+0.1 % end to end, profiles/r05_ab_ffout_reverse_order.log: inside run-to-run noise,
+  // hence restricted to the shape it was measured on; the permutation is a bijection of the tile order, results are unaffected).
+  // MD_SP_REVERSE = 0 switches it off, 2 restores the round-5 rule (every plain GEMM with A > 256 MiB).
   static const int rev = md_env_int("MD_SP_REVERSE", 1);
-  p.reverse = !CONV && !GEGLU && rev && !p.bias_rows && (size_t)p.M * (size_t)p.lda * 2 > ((size_t)256 << 20);
+  const bool big_a = (size_t)p.M * (size_t)p.lda * 2 > ((size_t)256 << 20);
+  p.reverse = !CONV && !GEGLU && !p.bias_rows && big_a && (rev == 2 || (rev == 1 && p.K >= 4 * p.N));
   const int ncu = md_device_cus();
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
   hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);

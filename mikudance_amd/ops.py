@@ -110,9 +110,16 @@ def conv3x3(x, w, cout, bias=None, residual=None, rowadd=None, rows_per_group=0,
     return out
 
 
-def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False):
-    """True when md_gemm_ln_f16 has a kernel for the problem (else: layernorm + gemm on the unfolded weights)."""
-    return bool(_lib.load().md_gemm_ln_plan(M, N, K, act, 2 if rowadd else 0))
+def _dense16(t):
+    """The fused streaming kernels fetch whole 16-byte pieces of every row: base 16-byte aligned, row pitch a multiple of 8 elements."""
+    return t is None or (t.data_ptr() % 16 == 0 and t.stride(-2) % 8 == 0 and t.stride(-1) == 1)
+
+
+def gemm_ln_plan(M, N, K, act=ACT_NONE, rowadd=False, a=None):
+    """True when md_gemm_ln_f16 has a kernel for the problem (else: layernorm + gemm on the unfolded weights).  The C-side query answers
+    for dense, 16-byte aligned operands; `a` (the token matrix about to be passed) adds the pointer / pitch check, so that a channel- or
+    row-sliced operand with an odd offset takes the literal pair instead of failing with MD_ERR_ARG."""
+    return _dense16(a) and bool(_lib.load().md_gemm_ln_plan(M, N, K, act, 2 if rowadd else 0))
 
 
 def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, out=None):
@@ -126,6 +133,8 @@ def gemm_ln(a, wf, sc, eps=1e-5, rowadd=None, rows_per_group=0, act=ACT_NONE, ou
         out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), device=a.device, dtype=F16)
     ldc = _rowmajor(out, "out")
     ldra = _rowmajor(rowadd, "rowadd") if rowadd is not None else 0
+    if rowadd is not None and (rows_per_group <= 0 or rowadd.shape[0] * rows_per_group < M or rowadd.shape[1] < N):
+        raise _lib.MdanceHipError(f"gemm_ln: row term {tuple(rowadd.shape)} does not cover M={M} rows in groups of {rows_per_group} x N={N}")
     _lib.call("md_gemm_ln_f16", a.data_ptr(), lda, wf.data_ptr(), sc.data_ptr(), out.data_ptr(), ldc, M, N, K, float(eps), _p(rowadd), ldra,
               rows_per_group, act, _st(),
               meta=(f"gemm M={M} N={N} K={K}" + (" geglu" if act == ACT_GEGLU else "") + " ln", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
@@ -145,8 +154,9 @@ def _gn_workspace(x, B, HW, C, groups):
     return ws
 
 
-def gemm_affine_plan(M, N, K, rows_per_image):
-    return bool(_lib.load().md_gemm_affine_plan(M, N, K, rows_per_image))
+def gemm_affine_plan(M, N, K, rows_per_image, x=None):
+    """As gemm_ln_plan: `x` (the NHWC tensor or channel slice about to be passed) adds the alignment check the C-side query cannot make."""
+    return _dense16(x) and bool(_lib.load().md_gemm_affine_plan(M, N, K, rows_per_image))
 
 
 def groupnorm_table(x, gamma, beta, groups, eps):
