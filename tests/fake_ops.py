@@ -328,6 +328,19 @@ def require_gpu(t, who):
     pass
 
 
+_NAMES = ("gemm", "gemm_ln_plan", "gemm_ln", "gemm_affine_plan", "groupnorm_table", "gemm_affine", "conv3x3", "groupnorm", "layernorm", "instnorm_spade",
+          "attention", "softmax_rows_", "temporal_attention", "pack_nhwc", "unpack_nhwc", "concat_channels", "window_accumulate", "cfg_ddim_step",
+          "require_gpu")
+
+
+def install_process():
+    """The same replacement for a whole (spawned worker) process: no monkeypatch fixture there, and nothing to restore when it exits."""
+    from mikudance_amd import ops
+    for name in _NAMES:
+        setattr(ops, name, globals()[name])
+    del CALLS[:]
+
+
 def install(monkeypatch):
     """Replace the functions of mikudance_amd.ops by the emulations above for the duration of a test."""
     from mikudance_amd import ops

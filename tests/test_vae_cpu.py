@@ -172,3 +172,62 @@ def test_vae_oracle_against_independent_module_implementation(chans):
         assert (ref.moments(x) - O.vae_encode_moments(sd, x)).abs().max() < 1e-4
         assert (ref.decode(z) - O.vae_decode(sd, z)).abs().max() < 1e-4
         assert tuple(O.vae_decode(sd, z).shape) == (2, 3, 6 * 2 ** (len(chans) - 1), 5 * 2 ** (len(chans) - 1))
+
+
+# ---- the pipeline never encodes the same condition image twice (scripts/inference_video.py:156-180 substitutes F black frames each
+# for absent face / hand guidance: 2F of the 3F + 2 encodes of configs[1] are one image) ----
+class _CountingVAE(torch.nn.Module):
+    """A deterministic per-image VAE stand-in (conv + per-image normalisation) that counts the images it is asked to encode."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.w = torch.nn.Parameter(torch.randn(4, 3, 8, 8, generator=g) * 0.1)
+        self.seen = 0
+
+    dtype = property(lambda self: self.w.dtype)
+    device = property(lambda self: self.w.device)
+
+    def encode(self, x):
+        self.seen += x.shape[0]
+        z = torch.nn.functional.conv2d(x, self.w, stride=8)
+        z = z / (1.0 + z.flatten(1).abs().amax(1)[:, None, None, None])              # per-image arithmetic only
+        return type("E", (), {"latent_dist": type("D", (), {"mean": z})})
+
+
+def _pipe(vae):
+    from mikudance_amd import MikuDanceVideoPipeline
+    return MikuDanceVideoPipeline(vae=vae, image_encoder=None, reference_unet=None, denoising_unet=None, scheduler=None)
+
+
+def test_deduped_encodes_are_bit_identical():
+    F_ = 16
+    g = torch.Generator().manual_seed(0)
+    pose = [torch.rand(1, 3, 64, 64, generator=g) for _ in range(F_)]
+    black = lambda: [torch.zeros(1, 3, 64, 64) for _ in range(F_)]                       # distinct objects, same content
+    imgs = [torch.rand(1, 3, 64, 64, generator=g) * 2 - 1, torch.rand(1, 3, 64, 64, generator=g)] + pose + black() + black()
+    a, b = _CountingVAE(), _CountingVAE()
+    pa, pb = _pipe(a), _pipe(b)
+    pb.dedupe_encodes = False
+    la, lb = pa._encode_many(imgs), pb._encode_many(imgs)
+    assert torch.equal(la, lb) and la.shape == (3 * F_ + 2, 4, 8, 8)
+    assert b.seen == 3 * F_ + 2 and a.seen == F_ + 3                                     # 18 distinct images + one black frame
+    assert pa.last_encode_stats == dict(images=3 * F_ + 2, encoded=F_ + 3)
+    # configs[2]: every image distinct -> nothing is dropped, order unchanged
+    a.seen = 0
+    distinct = [torch.rand(1, 3, 64, 64, generator=g) for _ in range(10)]
+    assert torch.equal(pa._encode_many(distinct), pb._encode_many(distinct)) and a.seen == 10
+
+
+def test_unique_images_resolves_signature_collisions_and_repeats_anywhere():
+    from mikudance_amd import MikuDanceVideoPipeline
+    x = torch.zeros(7, 3, 4, 4)
+    x[1, 0, 0, 0], x[1, 0, 0, 2] = 1.0, -1.0          # same two partial sums as the black frames 0 / 3 (elements 0 and 2 are outside the 1::3 sum): a collision
+    x[2] = 0.5
+    x[4] = x[1]
+    x[5, 2, 3, 3] = float("nan")                       # an image holding a NaN is never equal to anything: its own representative
+    x[6] = 0.5
+    rep, inv = MikuDanceVideoPipeline._unique_images(x)
+    assert rep == [0, 1, 2, 5] and inv == [0, 1, 2, 0, 1, 3, 2]
+    rebuilt = x[torch.tensor(rep)][torch.tensor(inv)]
+    assert torch.equal(torch.nan_to_num(rebuilt, nan=7.0), torch.nan_to_num(x, nan=7.0))
