@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--small", action="store_true", help="reduced-width UNets (debug only; NOT the benchmark)")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 owns the batch and scatters the per-clip conditioning inside "
                     "the timed region (default: every rank stages its own clip before it)")
+    ap.add_argument("--window-parallel", action="store_true", help="N > 1: ONE clip, the context windows of every DDIM step shared out over the "
+                    "ranks (mikudance_amd.dp.WindowParallel: one all_reduce of the per-frame accumulators per step); strong scaling, meant for "
+                    "--config 4 (3 windows of 30 frames).  Default: one clip per rank (weak scaling, configs[3])")
     ap.add_argument("--dry-run-cpu", action="store_true", help="plumbing test only (tests/test_bench_contract_cpu.py): CPU + gloo, the "
                     "kernels replaced by a stand-in; the line says so and carries no roofline")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
@@ -114,13 +117,19 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
     # rank i: the conditioning of a clip is produced by the VAE / CLIP of the rank that denoises it), so the timed region holds
     # the denoising loop and ONE gather of the final latents.  --scatter: rank 0 owns the whole batch (BASELINE configs[3] as a
     # service front-end would see it) and the timed region adds ONE scatter of the per-clip conditioning (~8.5 MB per clip).
+    wp = None
+    if args.window_parallel:
+        assert not args.scatter, "--window-parallel replicates ONE clip on every rank: nothing to scatter"
+        wp = dp.WindowParallel()
     if args.scatter:
         staged = [tuple(t.to(dev) for t in make_clip(100 + r)) for r in range(world)] if rank == 0 else None
     else:
-        staged = tuple(t.to(dev) for t in make_clip(100 + rank))
+        staged = tuple(t.to(dev) for t in make_clip(100 + (0 if wp else rank)))     # window-parallel: the SAME clip on every rank
 
     def run(clips):
         lat, rl, emb = dp.scatter_clips(clips, dev) if args.scatter else clips
+        if wp is not None and not dry:
+            return [denoise(lat, rl, emb, args.ddim_steps, args.guidance, window_parallel=wp)]     # every rank holds the full result
         out = denoise(lat, rl, emb, args.ddim_steps, args.guidance)
         return dp.gather_latents(out)
 
@@ -133,10 +142,31 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
     for _ in range(args.steps):
         res = run(staged)
     sync()
+    own_elapsed = time.perf_counter() - t0                           # this rank's own time, before it waits for the others
     dp.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(elapsed, dev)
     n_ranks_seen = int(round(dp.sum_over_ranks(1.0, dev)))          # every rank of the job reached the end of the timed region
+
+    # Diagnostics of a multi-rank run, all OUTSIDE the timed region (the first real 8-GPU run must be readable without a second lease):
+    # who computed where (device UUID / PCI bus id per rank: N distinct GPUs, not LOCAL_RANK % device_count aliasing), each rank's own
+    # loop time, the collective library, and the scatter / gather of one batch timed on their own.
+    ident = dict(dp.device_identity(None if dry else dev), own_elapsed_s=own_elapsed, own_ms_per_step=own_elapsed / args.steps * 1e3)
+    comm_ms = {}
+    if world > 1:
+        for name, fn in (("gather_latents", lambda: dp.gather_latents(torch.zeros((1, 4, args.frames, h, w), device=dev, dtype=torch.float16))),
+                         ("scatter_clips", (lambda: dp.scatter_clips(staged, dev)) if args.scatter else None),
+                         ("window_all_reduce", (lambda: wp.reduce(torch.zeros((2, args.frames, h * w, 4), device=dev), torch.zeros((args.frames,), device=dev)))
+                          if wp is not None else None)):
+            if fn is None:
+                continue
+            fn()                                                     # first call: connection set-up
+            sync(); dp.barrier(); sync()
+            t1 = time.perf_counter()
+            fn()
+            sync()
+            comm_ms[name] = dp.max_over_ranks((time.perf_counter() - t1) * 1e3, dev)
+    per_rank = dp.gather_objects(ident)
 
     # Per-launch HIP-event instrumentation (roofline, kernel families, executed FLOPs) runs on ONE extra pass of the same
     # clip right after the timed region, on rank 0 only and without collectives: two event records per launch x ~17k launches
@@ -157,7 +187,11 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
 
     if rank != 0:
         return
-    assert len(res) == world and all(torch.isfinite(r.float()).all() for r in res), "missing or non-finite latents"
+    assert len(res) == (1 if wp else world) and all(torch.isfinite(r.float()).all() for r in res), "missing or non-finite latents"
+    gpus = [(r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device_index")) for r in per_rank]
+    multi = {"per_rank": per_rank, "n_distinct_gpus": len(set(gpus)) if not dry else None, "gpu_aliasing": (len(set(gpus)) < world) if not dry else None,
+             "collectives": dp.collective_library(), "comm_ms_outside_timed_region": comm_ms,
+             "mode": "window-parallel (one clip, windows of a step over ranks, all_reduce per step)" if wp else "clip data-parallel (one clip per rank)"}
     if dry:
         # plumbing line of the CPU test: same launch / collective / timing protocol, no kernels -> no throughput claim
         print(json.dumps({"metric": f"frames/sec ({args.size}x{args.size}, {args.frames}f, {args.ddim_steps} DDIM steps)", "value": None,
@@ -165,7 +199,7 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f16", "data": "dry-run (CPU + gloo plumbing test: kernels replaced by a stand-in, NOT a measurement)",
                           "config": {"workload": "dry-run", "parallelism": f"dp{world}", "input_staging": "scatter" if args.scatter else "rank-local"},
-                          "clips_gathered": len(res), "clip_means": [float(r.float().mean()) for r in res]}))
+                          "clips_gathered": len(res), "clip_means": [float(r.float().mean()) for r in res], "multi_gpu": multi}))
         return
     prof = _lib.PROFILER.summary()
     total_flops = sum(d["flops"] for d in prof.values()) / inst_steps
@@ -208,18 +242,18 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
                                                                       "FETCH_SIZE x2 (gfx950 correction, MI355X guide HBM section)")}
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
-    frames_total = args.frames * args.steps * world
+    frames_total = args.frames * args.steps * (1 if wp else world)   # window-parallel: ONE clip, whatever the rank count (strong scaling)
     value = frames_total / elapsed
     line = {
         "metric": f"frames/sec ({args.size}x{args.size}, {args.frames}f, {args.ddim_steps} DDIM steps)", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "n_ranks_seen": n_ranks_seen,
+        "scaling": "strong" if wp else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "n_ranks_seen": n_ranks_seen,
         "config": {"workload": f"configs[{args.config}]: {args.size}x{args.size}, {args.frames}-frame clip, {args.ddim_steps} DDIM steps, fp16, "
                                "reference_unet + denoising_unet + motion_module, CFG 3.5, one clip per GPU per step"
                                + (", full guidance: scene-motion flow from the demo camera tracks (tests/golden/g2) through "
                                   "camera_to_scene_motion + non-zero face/hand latents" if args.config == 2 else "")
                                + (", context 30 / overlap 8 -> 3 wrapping windows, 60-frame UNet batches" if args.config == 4 else ""),
-                   "parallelism": f"dp{world}", "input_staging": "scatter from rank 0 inside the timed region" if args.scatter
+                   "parallelism": (f"wp{world}" if wp else f"dp{world}"), "input_staging": "scatter from rank 0 inside the timed region" if args.scatter
                    else "rank-local (every rank stages its own clip in HBM before the timed region)", "reference_reuse": pipe.reference_reuse, "weights": "random-init SD-1.5 geometry "
                    "(N(0,1/fan_in), seeds 1234/4321)", "width": "reduced(debug)" if args.small else "full"},
         "executed_tflop_per_clip": total_flops / 1e12, "mfma_frac_whole_loop": total_flops / (elapsed / args.steps) / PEAK_MFMA_F16,
@@ -231,6 +265,7 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
                                     gbps=v["bytes"] / (v["ms"] * 1e-3) / 1e9,
                                     launches=v["count"] // inst_steps) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
         "roofline": roofline,
+        "multi_gpu": multi,
     }
     top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]
     line["top_launch_shapes"] = [dict(label=k, ms_per_clip=v["ms"] / inst_steps, launches=v["count"] // inst_steps,
@@ -247,9 +282,14 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
         # src/pipelines/pipeline_mikudance.py:456-549 and :115-130), batches of 8 images as the product pipeline issues them
         del ref, den, pipe
         torch.cuda.empty_cache()
-        vae_ms = vae_ms_per_clip(dev, args.size, args.frames)
-        line["vae_ms_per_clip"] = vae_ms
-        line["e2e_frames_per_s"] = args.frames / (elapsed / args.steps + vae_ms * 1e-3)
+        vae = vae_ms_per_clip(dev, args.size, args.frames)
+        # the loop's time is the same for configs[1] and configs[2] (same shapes); the VAE's is not: absent face / hand guidance is 2F copies
+        # of one black frame, encoded once
+        mine = "configs[2]" if args.config == 2 else "configs[1]"
+        line["vae_ms_per_clip"] = vae[mine]["ms"]
+        line["vae_by_config"] = vae
+        line["e2e_frames_per_s"] = args.frames / (elapsed / args.steps + vae[mine]["ms"] * 1e-3)
+        line["e2e_frames_per_s_by_config"] = {k: args.frames / (elapsed / args.steps + v["ms"] * 1e-3) for k, v in vae.items()}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ref_sd, den_sd, args, ctx)
     print(json.dumps(line))
@@ -331,34 +371,44 @@ def full_guidance(ref_latents, frames, h, w):
 
 
 def vae_ms_per_clip(dev, size, frames, batch=8):
-    """AutoencoderKL (sd-vae-ft-mse geometry, seeded random weights) at the benchmark size: F decodes + 3F + 2 encodes in batches of
-    8 images, median of three wall-clock passes after a warm-up pass.  Images and latents are device-resident when a pass starts
-    (like `value`: the product's _encode_many additionally copies each 8-image batch host -> device, 9.4 MB per image, which is
-    NOT in this figure).  Not part of `value` (the metric is the denoising loop)."""
-    from mikudance_amd import AutoencoderKL
+    """AutoencoderKL (sd-vae-ft-mse geometry, seeded random weights) at the benchmark size through the PRODUCT's own calls: F decodes in
+    batches of 8 + MikuDanceVideoPipeline._encode_many over the 3F + 2 condition images (batches of 8, an image that occurs several times is
+    encoded once).  Two input sets, median of three wall-clock passes each after a warm-up pass:
+      configs[1]  pose frames distinct, face / hand guidance absent = 2F black frames (scripts/inference_video.py:156-180): F + 3 encodes
+      configs[2]  every image distinct: 3F + 2 encodes
+    Images and latents are device-resident when a pass starts (like `value`; the host -> device copy of the images, 3.5 MB each in fp16,
+    is not in these figures).  Not part of `value` (the metric is the denoising loop)."""
+    from mikudance_amd import AutoencoderKL, MikuDanceVideoPipeline
     from mikudance_amd.synth import synth_state_dict
     vae = AutoencoderKL()
     vae.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed=77), strict=True)
     vae = vae.half().to(dev).eval()
+    pipe = MikuDanceVideoPipeline(vae, None, None, None, None)
+    pipe.vae_batch = batch
     g = torch.Generator(device=dev).manual_seed(7)
     lat = torch.randn(frames, 4, size // 8, size // 8, device=dev, generator=g).half()
-    imgs = (torch.rand(3 * frames + 2, 3, size, size, device=dev, generator=g) * 2 - 1).half()
-
-    def once():
-        for i in range(0, frames, batch):
-            vae.decode(lat[i:i + batch]).sample
-        for i in range(0, imgs.shape[0], batch):
-            vae.encode(imgs[i:i + batch]).latent_dist.mean
-    times = []
+    distinct = (torch.rand(3 * frames + 2, 3, size, size, device=dev, generator=g) * 2 - 1).half()
+    black = distinct.clone()
+    black[2 + frames:] = 0                                               # face + hand: the script's Image.new("RGB", size, (0, 0, 0))
+    out = {}
     with torch.no_grad():
-        once()                                                           # warm-up: allocator growth, packed weights
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            once()
-            torch.cuda.synchronize()
-            times.append((time.perf_counter() - t0) * 1e3)
-    return sorted(times)[1]                                              # median of three
+        for name, imgs in (("configs[1]", black), ("configs[2]", distinct)):
+            views = [imgs[i:i + 1] for i in range(imgs.shape[0])]        # one tensor per image, as __call__ hands them over
+
+            def once():
+                for i in range(0, frames, batch):
+                    vae.decode(lat[i:i + batch]).sample
+                pipe._encode_many(views)
+            once()                                                       # warm-up: allocator growth, packed weights
+            times = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                once()
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) * 1e3)
+            out[name] = dict(ms=sorted(times)[1], **pipe.last_encode_stats)       # median of three
+    return out
 
 
 def cpu_quota(root="/sys/fs/cgroup"):
@@ -422,19 +472,32 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
         torch.set_num_threads(avail)
         O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)             # warm-up (untimed)
         sweep2 = {}
-        for n in sorted({n for n in (16, 32, 64, avail) if n <= avail}, reverse=True):
+        q_raw0, q_cpus0 = cpu_quota()
+        counts = (16, 32, 64, avail) if not q_cpus0 else (int(q_cpus0 + 0.5), 2 * int(q_cpus0 + 0.5), avail)   # a quota: the quota, twice it, everything
+        for n in sorted({n for n in counts if 0 < n <= avail}, reverse=True):
             torch.set_num_threads(n)
             t0 = time.perf_counter()
             O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
             sweep2[n] = time.perf_counter() - t0
         best = min(sweep2, key=sweep2.get)
-        if os.environ.get("MD_CPU_WORKER_THREADS"):                      # experiments / tests: pin the per-worker thread count
-            best = int(os.environ["MD_CPU_WORKER_THREADS"])
+        forced = os.environ.get("MD_CPU_WORKER_THREADS")
+        if forced:                                                       # experiments / tests: pin the per-worker thread count (recorded in the line)
+            best = int(forced)
             torch.set_num_threads(best)
             t0 = time.perf_counter()
             O.denoise_loop(ref_sd, den_sd, lat, rl, emb, 1, guidance_scale=args.guidance)
             sweep2[best] = time.perf_counter() - t0
         dt2 = sweep2[best]
+        # (2b) the extrapolation shown, not assumed (SURVEY.md 8d asked for one full step): ONE step of FOUR frames on the same thread count.
+        # `value` stays the one-frame figure only if this is within 10 % of 4 x the one-frame step; otherwise the four-frame step is the sample.
+        f4 = 4
+        torch.set_num_threads(best)
+        lat4, rl4, emb4 = synth_inputs(f4, h, w, ctx_len=full_ctx[0], ctx_dim=full_ctx[1], seed=100)
+        t0 = time.perf_counter()
+        O.denoise_loop(ref_sd, den_sd, lat4, rl4, emb4, 1, guidance_scale=args.guidance)
+        dt2_f4 = time.perf_counter() - t0
+        lin = dt2_f4 / (f4 * dt2)                                        # 1.0 = exactly linear in the frame count
+        linear_ok = abs(lin - 1.0) <= 0.10
         # (3) ALL usable cores.  "Usable" = min(CPU affinity, cgroup CPU quota): on the GPU boxes of this pool the host has 128 cores / 256
         # hardware threads and the container a quota of 16 CPUs (cpu.max "1600000 100000"), which is why 16 intra-op threads are best and
         # every further thread only adds throttling.  When the quota leaves room for more than one `best`-thread worker, P = usable // best
@@ -454,12 +517,14 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
         from concurrent.futures import ThreadPoolExecutor
         dt3 = None
         if P > 1:
+            with ThreadPoolExecutor(P) as ex:                            # untimed: every worker thread builds its OpenMP team and touches its buffers
+                list(ex.map(worker, range(P)))
             t0 = time.perf_counter()
             with ThreadPoolExecutor(P) as ex:
                 list(ex.map(worker, range(P)))
             dt3 = time.perf_counter() - t0
         torch.set_num_threads(avail)
-    single = f / (dt2 * args.ddim_steps)
+    single = f / (dt2 * args.ddim_steps) if linear_ok else f4 / (dt2_f4 * args.ddim_steps)
     allcore = P * f / (dt3 * args.ddim_steps) if dt3 else single
     eff = (dt2 / dt3) if dt3 else 1.0                                     # 1.0 = P workers finish in the time of one
     use_all = allcore > single
@@ -478,7 +543,9 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
     quota = quota_raw
     return {"value": allcore if use_all else single, "unit": "frames/s", "cores": P * best if use_all else best, "physical_cores": physical,
             "usable_cores": usable, "affinity": affinity, "cgroup_cpu_max": quota, "cgroup_quota_cpus": quota_cpus, "kind": "port",
-            "single_process": {"frames_per_s": single, "threads": best, "s_per_frame_step": round(dt2, 2)},
+            "single_process": {"frames_per_s": single, "threads": best, "s_per_frame_step": round(dt2, 2), "threads_forced_by_env": bool(forced)},
+            "frames_linearity": {"s_per_step_1_frame": round(dt2, 2), "s_per_step_4_frames": round(dt2_f4, 2), "ratio_to_linear": round(lin, 3),
+                                 "within_10_percent": linear_ok, "value_from": "1-frame step" if linear_ok else "4-frame step"},
             "all_cores": {"workers": P, "threads_per_worker": best, "s_for_all_workers": round(dt3, 2) if dt3 else None,
                           "frames_per_s": allcore, "parallel_efficiency": round(eff, 3)},
             "thread_sweep_s_per_step_at_size": {str(k): round(v, 2) for k, v in sorted(sweep2.items())},
@@ -487,10 +554,11 @@ def cpu_baseline(ref_sd, den_sd, args, ctx):
             "sample": f"after one warm-up pass each: (1) configs[0] in full (256x256, 4 frames, 4 DDIM steps, fp32, literal algorithm) on {threads} "
                       f"intra-op threads (best of the sweep) = {dt1:.1f} s; (2) 1 DDIM step of {f} frame at {args.size}x{args.size} (reference_unet + "
                       f"denoising_unet, CFG pair, fp32, full-width random-init weights, literal algorithm) timed on "
-                      f"{'/'.join(str(k) for k in sorted(sweep2))} threads, best = {best} threads = {dt2:.1f} s; (3) the same frame-step on "
+                      f"{'/'.join(str(k) for k in sorted(sweep2))} threads, best = {best} threads{' (forced by MD_CPU_WORKER_THREADS)' if forced else ''} = {dt2:.1f} s; "
+                      f"(2b) 1 DDIM step of {f4} frames on {best} threads = {dt2_f4:.1f} s = {lin:.2f} x linear; (3) the same frame-step on "
                       f"{P} independent frame(s) at once, {best} threads each = {P * best} of {usable} usable cores; value = "
-                      f"{'(3)' if use_all else '(2)'}: frames / ({args.ddim_steps} steps x wall time), one frame-step extrapolated linearly over "
-                      f"frames and steps.  Cores: {why}"}
+                      f"{'(3)' if use_all else '(2)'}: frames / ({args.ddim_steps} steps x wall time), the {'one' if linear_ok else 'four'}-frame step extrapolated linearly over "
+                      f"frames and steps (measured: 4 frames = {lin:.2f} x 4 one-frame steps).  Cores: {why}"}
 
 
 if __name__ == "__main__":

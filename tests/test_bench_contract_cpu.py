@@ -115,6 +115,13 @@ def test_two_rank_launch_protocol_under_gloo():
         assert d["value"] is None and "dry-run" in d["data"] and d["config"]["parallelism"] == "dp2"
         assert d["config"]["input_staging"] == ("scatter" if extra else "rank-local")
         assert d["clip_means"][0] != d["clip_means"][1]                  # two different clips (seeds 100, 101) came back in rank order
+        # diagnostics of a multi-rank run: one record per rank (own loop time, who computed where), the collective library, and the
+        # scatter / gather of one batch timed on their own outside the timed region
+        m = d["multi_gpu"]
+        assert [r["rank"] for r in m["per_rank"]] == [0, 1] and len({r["pid"] for r in m["per_rank"]}) == 2
+        assert all(r["own_elapsed_s"] > 0 and r["own_ms_per_step"] <= d["ms_per_step"] * 1.0001 for r in m["per_rank"])
+        assert m["collectives"]["backend"] == "gloo" and m["collectives"]["world"] == 2 and m["mode"].startswith("clip data-parallel")
+        assert m["comm_ms_outside_timed_region"]["gather_latents"] > 0 and ("scatter_clips" in m["comm_ms_outside_timed_region"]) == bool(extra)
 
 
 def test_eight_rank_launch_protocol_under_gloo():
@@ -133,6 +140,7 @@ def test_eight_rank_launch_protocol_under_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["clips_gathered"] == 8 and d["config"]["parallelism"] == "dp8"
     assert len(set(d["clip_means"])) == 8                               # eight different clips (seeds 100 .. 107) came back
+    assert [r["local_rank"] for r in d["multi_gpu"]["per_rank"]] == list(range(8))
 
 
 def test_cpu_quota_parsing(tmp_path):
