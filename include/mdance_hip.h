@@ -176,6 +176,14 @@ int md_cfg_ddim_step(void* latents, const void* noise_sum, const void* counter, 
 int md_cfg_ddim_step_eta(void* latents, const void* noise_sum, const void* counter, const void* variance_noise, int Ftot, int HW,
                          int halves, float guidance, float alpha_t, float alpha_prev, float eta, void* stream);
 
+/* Persistent launchers (gemm_sp_kernel behind md_gemm_f16 / md_conv*_f16) start one workgroup per CU of the device.  A caller that launches
+ * on a stream created with a CU mask (hipExtStreamCreateWithCUMask: a partition of the chip shared with another stream) tells the
+ * library how many CUs that stream owns: grids and the tile-choice model then use `ncu` (a multiple of 8: the same number of CUs on each
+ * of the 8 XCDs, which also keeps workgroup b on XCD b % 8) until md_set_cu_limit(0) restores the device's own count.  Process-wide, not
+ * per stream; the streaming kernels (K = 320 / 640 projections) keep their 256-workgroup grids.  tools/cu_partition.py is the user
+ * (profiles/r06_ab_cu_partition.log).  Returns MD_OK, or MD_ERR_ARG for a negative count or one that is not a multiple of 8. */
+int md_set_cu_limit(int ncu);
+
 /* Dispatch queries (no device access, nothing launched): which kernel the automatic dispatch of md_gemm_f16 / md_conv3x3_nhwc_f16
  * selects for a problem on a chip with `ncu` compute units, for dense 16-byte aligned operands.  epi: bit 0 residual, bit 1
  * row-broadcast operand, bit 2 bias.  Returns 1MN gemm_sp_kernel with wave tile (MT, NT) = (M, N) (135 = 192x320, 134 = 192x256,

@@ -21,6 +21,7 @@ SIGNATURES = {
                                         c_int, c_int, c_int, P]),
     "md_conv_nhwc_f16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
                                  c_int, c_int, c_int, P]),
+    "md_set_cu_limit": (c_int, [c_int]),
     "md_gemm_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "md_conv3x3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "md_softmax_rows_f16": (c_int, [P, c_int, c_int, c_int, c_float, P]),

@@ -327,6 +327,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn2_kernel(AttnParams p) {
               pf[u][sub * 2 + (r >> 3)][r & 7] = (half_t)__builtin_amdgcn_exp2f(s[u][sub][r]);
               pf[u][sub * 2 + (r >> 3)][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(s[u][sub][r + 1]);
             }
+#ifdef MD_DEGRADE_P8
+          // DIAGNOSTIC build only (tools/build_ab.sh, never shipped): P keeps 8 of its 11 significant bits -- a deliberately degraded
+          // kernel that the parity budgets of tests/parity_budget.py must catch (profiles/r06_parity_budget_degraded.log)
+          typedef unsigned uint4d __attribute__((ext_vector_type(4)));
+#pragma unroll
+          for (int t = 0; t < 4; ++t) pf[u][t] = __builtin_bit_cast(half8_t, __builtin_bit_cast(uint4d, pf[u][t]) & 0xfff8fff8u);
+#endif
         };
         typedef unsigned uint4v __attribute__((ext_vector_type(4)));
         const bool first = it == 0;

@@ -74,7 +74,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 // output instead of ~26 for the 7.1.26 form used until round 2 (one v_rcp + one v_exp + 9 scalar FMAs) -- the GEGLU epilogues are
 // VALU bound.  The product h * gelu(g) is formed in fp32 and rounded once.
 typedef float float2_t __attribute__((ext_vector_type(2)));
+#ifdef MD_DEGRADE_GELU_TANH
+// DIAGNOSTIC build only (tools/build_ab.sh, never shipped): the tanh approximation of GELU instead of the exact erf form -- a deliberately
+// degraded epilogue that the parity budgets of tests/parity_budget.py must catch (profiles/r06_parity_budget_degraded.log)
+__device__ __forceinline__ float md_gelu_tanh(float x) {
+  const float u = 0.7978845608f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + (1.f - 2.f / (__expf(2.f * u) + 1.f)));
+}
+#endif
 __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
+#ifdef MD_DEGRADE_GELU_TANH
+  return float2_t{md_gelu_tanh(x.x), md_gelu_tanh(x.y)};
+#endif
   const float2_t ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
   float2_t p = float2_t{5.621299664e-06f, 5.621299664e-06f};
   p = p * ax + float2_t{5.105520901e-05f, 5.105520901e-05f};
@@ -99,6 +110,11 @@ __device__ __forceinline__ float2_t gelu_fast2(float2_t x) {
 // 6 + 4 + 1 + 1 dependent packed operations of a single chain (the compiler emits them back to back with s_nop between them).
 template <int N>
 __device__ __forceinline__ void gelu_fast2_x(float2_t (&x)[N]) {
+#ifdef MD_DEGRADE_GELU_TANH
+#pragma unroll
+  for (int c = 0; c < N; ++c) x[c] = float2_t{md_gelu_tanh(x[c].x), md_gelu_tanh(x[c].y)};
+  return;
+#endif
   float2_t ax[N], p[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
@@ -534,8 +550,20 @@ static void launch_variant(GemmParams& p, hipStream_t stream) {
 static int env_int(const char* name, int dflt) { return md_env_int(name, dflt); }
 
 
+// Streams created with a CU mask (hipExtStreamCreateWithCUMask) own fewer CUs than the device has: the persistent launchers size their
+// grids -- and the rounds model its tile choice -- for md_set_cu_limit's count instead (process-wide; 0 = the device's own count).
+static std::atomic<int> g_cu_limit{0};
+
+extern "C" int md_set_cu_limit(int ncu) {
+  if (ncu < 0 || (ncu & 7)) return MD_ERR_ARG;                    // the XCD-aware tile order needs whole multiples of the 8 XCDs
+  g_cu_limit.store(ncu, std::memory_order_relaxed);
+  return MD_OK;
+}
+
 static int md_device_cus() {
   // CU count of the CURRENT device, cached per device (a process may drive several GPUs)
+  const int lim = g_cu_limit.load(std::memory_order_relaxed);
+  if (lim > 0) return lim;
   static std::atomic<int> cache[64];
   int dev = 0;
   (void)hipGetDevice(&dev);

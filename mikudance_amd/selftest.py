@@ -121,4 +121,5 @@ def smoke():
         want = O.denoise_loop(ref_sd, den_sd, latents, ref_latents, embeds, 2, guidance_scale=3.5, reduced=True)
     r, c = rel_l2(out.float(), want), cosine(out.float(), want)
     print(json.dumps({"smoke": "denoise 2 steps, 4 frames, 16x16 latents, reduced-width UNets", "rel_l2": r, "cosine": c}))
-    assert r < 3e-2 and c > 0.999, (r, c)
+    # SURVEY 8c's bound is 3e-2; this configuration measures 7.1e-3 (GPUTEST_r05.json): 2x that is the regression guard (tests/parity_budget.py)
+    assert r < 1.5e-2 and c > 0.999, (r, c)

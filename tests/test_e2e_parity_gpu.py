@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline  # noqa: E402
 from mikudance_amd.selftest import SCHED_KWARGS, build_models, cosine, rel_l2  # noqa: E402
 from oracle import cpu_ref as O  # noqa: E402
+from parity_budget import check as budget  # noqa: E402
 
 
 def test_20_steps_full_width_96x96_vs_fp32_restatement(full):
@@ -32,6 +33,8 @@ def test_20_steps_full_width_96x96_vs_fp32_restatement(full):
     # fp16 itself: the product's distance from fp32 stays within 1.5x of what operator-by-operator fp16 rounding costs
     assert h["rel_l2"] <= 1.5 * y["rel_l2"] + 2e-3, (h["rel_l2"], y["rel_l2"])
     assert max(h["per_step_rel_l2"]) <= 3e-2, h["per_step_rel_l2"]
+    budget("e2e.f4_20steps_96x96_final", h["rel_l2"])
+    budget("e2e.f4_20steps_96x96_first_step", h["per_step_rel_l2"][0])
 
 
 @pytest.fixture(scope="module")
@@ -61,3 +64,4 @@ def test_reduced_width_long_schedules_three_wrapping_windows_vs_cpu_oracle(small
     print(f"\nE2E_SMALL steps={steps} per-step rel-L2 " + " ".join(f"{e:.2e}" for e in per_step))
     r, c = rel_l2(out.float(), want), cosine(out.float(), want)
     assert r <= 3e-2 and c >= 0.999, (r, c)
+    budget(f"e2e.small_three_windows_{steps}steps", r)

@@ -68,3 +68,5 @@ def test_config5_one_step_of_its_30_step_schedule_vs_fp32_restatement(full):
     h = rec["hip_vs_o32"]
     assert rec["config"]["steps_executed"] == [1, 2] and len(h["per_step_rel_l2"]) == 1
     assert h["rel_l2"] <= 3e-2 and h["cosine"] >= 0.999, h
+    from parity_budget import check as budget
+    budget("cfg4.one_window_30f_step2_of_30", h["rel_l2"])

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline, ReferenceAttentionControl  # noqa: E402
 from mikudance_amd.selftest import SCHED_KWARGS, build_models, cosine, rel_l2  # noqa: E402
 from oracle import cpu_ref as O  # noqa: E402
+from parity_budget import check as budget  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -56,6 +57,7 @@ def test_g4_unets_literal_call_pattern(small):
     reader.clear(); writer.clear()
     r, c = rel_l2(pred.float(), t["g4.pred"]), cosine(pred.float(), t["g4.pred"])
     assert r < 3e-2 and c > 0.999, (r, c)
+    budget("g4.pred", r)
 
 
 @pytest.mark.parametrize("reuse", [True, False])
@@ -74,6 +76,7 @@ def test_g5_loop_vs_reference_golden(small, reuse):
         assert r < 3e-2 and c > 0.999, (ts, r, c)
     last = t[f"g5.latents_after_t{g5['timesteps'][-1]}"]
     assert rel_l2(out.float(), last) < 3e-2
+    budget("g5.loop_final", rel_l2(out.float(), last))
 
 
 def test_loop_single_window_vs_oracle(small):
@@ -112,6 +115,7 @@ def test_g13_no_cfg_loop_vs_reference_golden(small, golden_dir, reuse):
         want = O.denoise_loop(ref_sd, den_sd, t["in.latents"], t["in.ref_latents"], emb, g13["steps"], guidance_scale=1.0,
                               context_frames=g13["context_frames"], context_overlap=g13["overlap"], reduced=True)
     assert rel_l2(out.float(), want) < 3e-2 and cosine(out.float(), want) > 0.999
+    budget("g13.no_cfg_loop_final", rel_l2(out.float(), want))
 
 
 def test_non_square_latents_and_odd_frame_count_vs_oracle(small):
@@ -273,6 +277,7 @@ def test_g8_full_width_unets_vs_reference_golden(full, golden_dir):
     pred = _literal_pair(ref, den, lat, rl, emb, f, h, w, meta["timestep"])
     r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
     assert r < 3e-2 and c > 0.999, (r, c)
+    budget("g8.full_width_pred", r)
 
 
 def test_g9_full_size_unets_vs_reference_golden(full, golden_dir):
@@ -290,6 +295,7 @@ def test_g9_full_size_unets_vs_reference_golden(full, golden_dir):
     pred = _literal_pair(ref, den, lat, rl, emb, f, h, w, meta["timestep"])
     r, c = rel_l2(pred.float(), gold), cosine(pred.float(), gold)
     assert r < 3e-2 and c > 0.999, (r, c)
+    budget("g9.full_size_pred", r)
 
 
 def test_g9_full_size_sp_kernels_vs_reference_golden(golden_dir, tmp_path):
@@ -308,6 +314,7 @@ def test_g9_full_size_sp_kernels_vs_reference_golden(golden_dir, tmp_path):
     gold = load_file(os.path.join(golden_dir, "g9_fullsize_pred.safetensors"))["g9.pred"].float()
     r_, c = rel_l2(pred, gold), cosine(pred, gold)
     assert r_ < 3e-2 and c > 0.999, (r_, c)
+    budget("g9.full_size_pred_sp_everywhere", r_)
 
 
 def test_g10_odd_latent_size_vs_reference_golden(small, golden_dir):

@@ -1,0 +1,81 @@
+#!/bin/bash
+# Round 6: ONE parameterised script for every GPU call.   gpurun -- 'bash tools/r06_gpu.sh TAG step [step ...]'
+# Each step writes under gpurun_out/TAG/ and is bounded by its own timeout.  Steps:
+#   suite         the -m gpu suite as the driver runs it (+ smoke), wall time recorded
+#   budget        record the parity budgets (tests/parity_budget.py) of the loop / UNet parity tests into gpurun_out/TAG/parity_budget.json
+#   degraded      the same tests on the two deliberately degraded builds (tools/ab/lib_degrade_{p8,gelu}.so) against the recorded budgets
+#   e2e           tests/e2e_parity.py at the headline configuration (f = 16, 20 steps, 96 x 96) -> e2e_parity.json
+#   bench         bench.py in full (per-shape dump) -> bench_cfg1.json ; bench2 / bench4: configs 2 / 4
+#   prof          rocprofv3 --kernel-trace --stats of bench.py --steps 1 -> kernel_stats.md
+#   cumask        tools/ubench/cu_mask_map.hip (mask bit -> CU calibration) + tools/cu_partition.py  (LAST: masked queues are new ground)
+#   kern ARGS     tools/bench_kernels.py with MD_KERN="gemm shapes ..." (30 iterations)
+#   ab            same-box end-to-end A/B of the libraries named in MD_AB="base cand" (tools/ab/lib_*.so), two rounds, family table
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-.}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+SUBSET="tests/test_unets_gpu.py tests/test_e2e_parity_gpu.py tests/test_full_size_gpu.py"
+summ() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); c = d.get("cpu_baseline") or {}; fam = d.get("kernel_families", {})
+        print(f.split("/")[-1], "%.3f f/s" % d["value"], "%.1f ms" % d["ms_per_step"], "e2e", d.get("e2e_frames_per_s_by_config") or d.get("e2e_frames_per_s"),
+              "frac", round(d["roofline"].get("frac", 0), 4), "cpu", c.get("value"), c.get("cores"), c.get("frames_linearity"),
+              " ".join("%s %.0f" % (k, v["ms_per_clip"]) for k, v in list(fam.items())[:8]))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+}
+for step in "$@"; do
+case $step in
+suite)
+  SECONDS=0; timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=12 > $O/pytest.log 2>&1; echo "pytest rc=$? wall ${SECONDS}s" | tee $O/pytest.time; tail -20 $O/pytest.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.log ;;
+budget)
+  rm -f $O/parity_budget.json
+  MD_PARITY_RECORD=$O/parity_budget.json timeout 1200 python -m pytest $SUBSET -q -m gpu -s > $O/pytest_budget.log 2>&1; echo "budget rc=$?"; tail -3 $O/pytest_budget.log
+  grep PARITY_MEASURE $O/pytest_budget.log | sort | uniq > $O/parity_measured.txt; cat $O/parity_measured.txt ;;
+degraded)
+  # the recorded budget becomes the suite's budget for this step (on the box only), then each degraded library takes the product's place
+  cp $O/parity_budget.json tests/golden/parity_budget.json
+  cp mikudance_amd/libmdance_hip.so /tmp/lib_keep.so
+  for v in degrade_p8 degrade_gelu; do
+    cp tools/ab/lib_$v.so mikudance_amd/libmdance_hip.so
+    timeout 1200 python -m pytest $SUBSET -q -m gpu -s > $O/pytest_$v.log 2>&1; echo "== $v rc=$? (non-zero = the budgets caught it)"
+    grep -E "PARITY_MEASURE|passed|failed" $O/pytest_$v.log | sort | uniq | tail -30
+  done 2>&1 | tee $O/degraded.log
+  cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so
+  timeout 1200 python -m pytest $SUBSET -q -m gpu > $O/pytest_real_vs_budget.log 2>&1; echo "real build vs recorded budget rc=$?" | tee -a $O/degraded.log; tail -2 $O/pytest_real_vs_budget.log ;;
+e2e)
+  SECONDS=0; timeout 1500 python tests/e2e_parity.py --frames 16 --steps 20 --out $O/e2e_parity.json > $O/e2e.log 2>&1; echo "e2e rc=$? wall ${SECONDS}s"; grep -v "^{" $O/e2e.log | tail -5
+  python -c "import json; d=json.load(open('$O/e2e_parity.json')); print({k: (v['rel_l2'], v['cosine']) for k, v in d.items() if isinstance(v, dict) and 'rel_l2' in v})" ;;
+bench)
+  SECONDS=0; MD_BENCH_DUMP=$O/shapes_all.txt timeout 1500 python bench.py > $O/bench_cfg1.json 2> $O/bench_cfg1.err; echo "cfg1 rc=$? wall ${SECONDS}s"; summ $O/bench_cfg1.json ;;
+bench2)
+  timeout 600 python bench.py --config 2 --no-cpu-baseline --no-pmc > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "cfg2 rc=$?"; summ $O/bench_cfg2.json ;;
+bench4)
+  MD_BENCH_DUMP=$O/shapes_cfg4.txt timeout 900 python bench.py --config 4 --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-pmc > $O/bench_cfg4.json 2> $O/bench_cfg4.err; echo "cfg4 rc=$?"; summ $O/bench_cfg4.json ;;
+prof)
+  cd /tmp && export TMPDIR=/tmp
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o prof -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-pmc > $O/prof_bench.json 2> $O/prof.err; echo "prof rc=$?"
+  cd $R
+  DB=$(ls $O/prof/*results.db 2>/dev/null | head -1)
+  [ -n "$DB" ] && python profiles/summarize_rocprof.py $DB $O/kernel_stats.md $O/prof_bench.json > /dev/null
+  rm -rf $O/prof; head -30 $O/kernel_stats.md ;;
+cumask)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 tools/ubench/cu_mask_map.hip -o /tmp/cu_mask_map && timeout 60 /tmp/cu_mask_map > $O/cu_mask_map.log 2>&1; echo "cu_mask_map rc=$?"; cat $O/cu_mask_map.log
+  timeout 400 python tools/cu_partition.py > $O/cu_partition.log 2> $O/cu_partition.err; echo "cu_partition rc=$?"; cat $O/cu_partition.log; tail -5 $O/cu_partition.err ;;
+kern)
+  MD_ITERS=${MD_ITERS:-30} MD_WARM=5 timeout 600 python tools/bench_kernels.py $MD_KERN 2>&1 | grep -v amdgpu | tee $O/kern.log ;;
+ab)
+  cp mikudance_amd/libmdance_hip.so /tmp/lib_keep.so
+  for r in 1 2; do for v in $MD_AB; do
+    cp tools/ab/lib_$v.so mikudance_amd/libmdance_hip.so
+    MD_BENCH_DUMP=$O/shapes_${v}_$r.txt timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc 2>/dev/null > $O/ab_${v}_$r.json; echo "== $v (round $r)"; summ $O/ab_${v}_$r.json
+  done; done 2>&1 | tee $O/ab.log
+  cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so ;;
+*) echo "unknown step $step" ;;
+esac
+done
