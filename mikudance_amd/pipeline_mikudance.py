@@ -83,6 +83,7 @@ class MikuDanceVideoPipeline:
         self.vae_scale_factor = 8
         self.vae_batch = 8                                                   # images per VAE call (the reference: 1)
         self.reference_reuse = True
+        self.share_first_layers = True                                       # denoising UNet: conv_in + first resnet once for both CFG halves
         self._device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
     # ------------------------------------------------------------------------------------------ plumbing
@@ -194,7 +195,9 @@ class MikuDanceVideoPipeline:
                     src = lat if whole else lat.index_select(0, win_long[wi])
                     x = ops.pack_nhwc(src, nb * f, f, (0, HW * 4, 1, ww * 4, 4), 0, 4, 64, hh, ww)
                     cross = den._cross(embeds[:nb], [i // f for i in range(nb * f)], dev)
-                    pred = den.forward_nhwc(x, nb, f, torch.full((nb,), float(t)), cross)
+                    # both clip-halves are packed from the SAME latents (batch stride 0 above): the layers in front of the first attention
+                    # run once (self.share_first_layers = False: the literal evaluation of both halves, bit-identical)
+                    pred = den.forward_nhwc(x, nb, f, torch.full((nb,), float(t)), cross, halves_identical=self.share_first_layers)
                     ops.window_accumulate(pred, noise_sum, counter, win_dev[wi], f, F_, HW, halves=nb)
                     reader.clear()
                     writer.clear()

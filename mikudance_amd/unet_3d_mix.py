@@ -308,8 +308,12 @@ class UNet3DConditionModel(_UNetBase):
         self._build(in_channels, tuple(block_out_channels), cross_attention_dim, norm_eps, flags, mm_kwargs, with_out=True)
 
     # ------------------------------------------------------------------------------------------ internal NHWC forward
-    def forward_nhwc(self, x, nb, f, timesteps, cross):
-        """x: (nb*f, h, w, 64) fp16 (4 latent channels, zero padded); returns pred tokens [(nb*f*h*w), 4]."""
+    def forward_nhwc(self, x, nb, f, timesteps, cross, halves_identical=False):
+        """x: (nb*f, h, w, 64) fp16 (4 latent channels, zero padded); returns pred tokens [(nb*f*h*w), 4].
+        halves_identical: the caller GUARANTEES that the two clip-halves of x hold the same latents (classifier-free guidance: the loop of
+        src/pipelines/pipeline_mikudance.py:626-633 feeds `torch.cat([latents] * 2)`) -- with equal timesteps, conv_in and the first resnet
+        (no attention in front of them: nothing has seen the context or the bank yet) then produce the same tensor for both halves, so
+        they run on ONE half and the result is copied (per-image arithmetic: bit-identical, tests/test_unets_gpu.py)."""
         pk = self.packed()
         dev = x.device
         _, hh, ww, _ = x.shape
@@ -319,13 +323,31 @@ class UNet3DConditionModel(_UNetBase):
         B = x.shape[0]
         c0 = self.conv_in.weight.shape[0]
         skips = _Skips(self._skip_plan())
-        x = ops.conv3x3(x, pk["cin"], c0, bias=pk["cinb"], out=skips.slot(B, hh, ww, c0, dev))
-        for blk in self.down_blocks:
+        tt = torch.as_tensor(timesteps).reshape(-1)
+        share = bool(halves_identical and nb == 2 and float(tt[0]) == float(tt[-1]))
+        if share:
+            slot = skips.slot(B, hh, ww, c0, dev)
+            ops.conv3x3(x[:f], pk["cin"], c0, bias=pk["cinb"], out=slot[:f])
+            slot[f:].copy_(slot[:f])
+            x = slot
+        else:
+            x = ops.conv3x3(x, pk["cin"], c0, bias=pk["cinb"], out=skips.slot(B, hh, ww, c0, dev))
+        for bi, blk in enumerate(self.down_blocks):
             for j, r in enumerate(blk.resnets):
                 H_, W_ = x.shape[1:3]
                 mm = blk.motion_modules[j]
                 dst = skips.slot(B, H_, W_, r.cout, dev)                 # the layer's LAST operator writes the skip in place
-                x = r(x, self._temb(pk, trows, r), f * H_ * W_, gf, out=None if (blk.has_cross_attention or mm is not None) else dst)
+                last_op = not (blk.has_cross_attention or mm is not None)
+                if share and bi == 0 and j == 0:
+                    # the first resnet on one half (time rows of group 0 = those of group 1), then both halves from the copy
+                    if last_op:
+                        r(x[:f], self._temb(pk, trows, r), f * H_ * W_, gf, out=dst[:f])
+                        dst[f:].copy_(dst[:f])
+                        x = dst
+                    else:
+                        x = r(x[:f], self._temb(pk, trows, r), f * H_ * W_, gf).repeat(2, 1, 1, 1)
+                else:
+                    x = r(x, self._temb(pk, trows, r), f * H_ * W_, gf, out=None if not last_op else dst)
                 if blk.has_cross_attention:
                     x = blk.attentions[j](x, cross, out=None if mm is not None else dst)
                 if mm is not None:

@@ -174,6 +174,23 @@ def test_run_to_run_bitwise_determinism(small):
     assert torch.equal(a, b)
 
 
+def test_layers_in_front_of_the_first_attention_run_once_for_both_cfg_halves(small, full):
+    """Both clip-halves of the denoising UNet's input are the same latents (reference pipeline_mikudance.py:626-633: torch.cat([latents] * 2))
+    and see the same timestep, so conv_in and the first resnet -- nothing in front of them has seen the context or the bank -- give the
+    same tensor twice: they run on one half and the result is copied.  Bit-identical to evaluating both halves (per-image arithmetic),
+    at reduced width and at the benchmark's own width and spatial size (the 192 x 320 conv tiles: M = 16 vs 32 images)."""
+    from mikudance_amd.synth import synth_inputs
+    meta, ref, den, ref_sd, den_sd, t = small
+    for (r_, d_), args in (((ref, den), (t["in.latents"][:, :, :4].cuda().half(), t["in.ref_latents"][:, :4].cuda().half(), t["in.embeds"].cuda().half(), 2, 3.5)),
+                           (full[:2], tuple(x.half().cuda() for x in synth_inputs(2, 96, 96, ctx_len=257, ctx_dim=768, seed=3)) + (1, 3.5))):
+        pipe = MikuDanceVideoPipeline(None, None, r_, d_, DDIMScheduler(**SCHED_KWARGS))
+        assert pipe.share_first_layers
+        a = pipe.denoise(*args)
+        pipe.share_first_layers = False
+        b = pipe.denoise(*args)
+        assert torch.equal(a, b)
+
+
 def test_zero_context_rows_skip_cross_attention(small):
     """The unconditional half's context is all zeros (reference pipeline_mikudance.py:418-423): K = V = 0, so cross-attention
     reduces to the to_out bias.  The shortcut must agree with the literal evaluation and must not trigger on non-zero rows."""
