@@ -11,6 +11,8 @@ from safetensors.torch import load_file
 
 pytestmark = pytest.mark.gpu
 
+from parity_budget import check_kernel  # noqa: E402
+
 from mikudance_amd import blocks  # noqa: E402
 from mikudance_amd.synth import synth_state_dict  # noqa: E402
 
@@ -20,6 +22,7 @@ def close(got, ref, what):
     err = (got - ref).abs().max().item()
     bound = 1e-2 * ref.abs().max().item() + 1e-3
     assert got.shape == ref.shape and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+    check_kernel(what, got, ref)
 
 
 def nhwc(x5):                      # (b, c, f, h, w) -> (b*f, h, w, c) fp16 on the GPU

@@ -15,6 +15,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from parity_budget import check_kernel  # noqa: E402
+
 from mikudance_amd import ops, packing  # noqa: E402
 
 
@@ -33,6 +35,7 @@ def close(got, ref, rtol=1e-2, atol=1e-3, what=""):
     err = (got.float() - ref.float()).abs().max().item()
     bound = rtol * ref.float().abs().max().item() + atol
     assert math.isfinite(err) and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+    check_kernel(what, value=float((got.float() - ref.float()).norm() / ref.float().norm()))     # on the device
 
 
 def _ln_ref(x, g, b, w, bias, eps=1e-5):

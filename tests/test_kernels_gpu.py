@@ -9,6 +9,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from parity_budget import check_kernel  # noqa: E402
+
 from mikudance_amd import ops, packing  # noqa: E402
 from oracle import cpu_ref as O  # noqa: E402
 
@@ -30,6 +32,7 @@ def close(got, ref, rtol=1e-2, atol=1e-3, what=""):
     err = (got - ref).abs().max().item()
     bound = rtol * ref.abs().max().item() + atol
     assert math.isfinite(err) and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+    check_kernel(what, got, ref)
 
 
 # --------------------------------------------------------------------------------------------- GEMM
@@ -432,6 +435,7 @@ def _close_dev(got, ref, rtol=1e-2, atol=1e-3, what=""):
     err = (got.float() - ref).abs().max().item()
     bound = rtol * ref.abs().max().item() + atol
     assert math.isfinite(err) and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+    check_kernel(what, value=float((got.float() - ref).norm() / ref.norm()))     # on the device: these operands are hundreds of MB
 
 
 @pytest.mark.parametrize("F_,HW,D", [(16, 9216, 40), (16, 2304, 80), (16, 576, 160), (30, 16384, 40), (30, 4096, 80), (30, 1024, 160)])

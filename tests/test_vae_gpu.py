@@ -10,6 +10,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from parity_budget import check_kernel  # noqa: E402
+
 from mikudance_amd import AutoencoderKL, ops, packing  # noqa: E402
 from mikudance_amd.selftest import cosine, rel_l2  # noqa: E402
 from mikudance_amd.synth import synth_state_dict  # noqa: E402
@@ -26,6 +28,7 @@ def close(got, ref, what):
     err = (got - ref).abs().max().item()
     bound = 1e-2 * ref.abs().max().item() + 1e-3
     assert got.shape == ref.shape and math.isfinite(err) and err <= bound, f"{what}: max err {err:.4g} > {bound:.4g}"
+    check_kernel(what, got, ref)
 
 
 @pytest.mark.parametrize("h,w,cin,cout", [(8, 8, 64, 64), (14, 10, 128, 192), (6, 12, 64, 320)])

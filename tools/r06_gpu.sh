@@ -9,6 +9,7 @@
 #   prof          rocprofv3 --kernel-trace --stats of bench.py --steps 1 -> kernel_stats.md
 #   cumask        tools/ubench/cu_mask_map.hip (mask bit -> CU calibration) + tools/cu_partition.py  (LAST: masked queues are new ground)
 #   kern ARGS     tools/bench_kernels.py with MD_KERN="gemm shapes ..." (30 iterations)
+#   trace         tools/sp_trace.py (needs tools/ab/lib_trace.so) on the shapes in MD_TRACE
 #   ab            same-box end-to-end A/B of the libraries named in MD_AB="base cand" (tools/ab/lib_*.so), two rounds, family table
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-.}
@@ -35,19 +36,20 @@ suite)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.log ;;
 budget)
   rm -f $O/parity_budget.json
-  MD_PARITY_RECORD=$O/parity_budget.json timeout 1200 python -m pytest $SUBSET -q -m gpu -s > $O/pytest_budget.log 2>&1; echo "budget rc=$?"; tail -3 $O/pytest_budget.log
-  grep PARITY_MEASURE $O/pytest_budget.log | sort | uniq > $O/parity_measured.txt; cat $O/parity_measured.txt ;;
+  MD_PARITY_RECORD=$O/parity_budget.json timeout 1500 python -m pytest tests -q -m gpu -s > $O/pytest_budget.log 2>&1; echo "budget rc=$?"; tail -3 $O/pytest_budget.log
+  grep PARITY_MEASURE $O/pytest_budget.log | sort | uniq > $O/parity_measured.txt; cat $O/parity_measured.txt
+  python -c "import json; d=json.load(open('$O/parity_budget.json')); print(len(d['checks']), 'loop/UNet budgets,', len(d['kernel_checks']), 'kernel budgets')" ;;
 degraded)
   # the recorded budget becomes the suite's budget for this step (on the box only), then each degraded library takes the product's place
   cp $O/parity_budget.json tests/golden/parity_budget.json
   cp mikudance_amd/libmdance_hip.so /tmp/lib_keep.so
   for v in degrade_p8 degrade_gelu; do
     cp tools/ab/lib_$v.so mikudance_amd/libmdance_hip.so
-    timeout 1200 python -m pytest $SUBSET -q -m gpu -s > $O/pytest_$v.log 2>&1; echo "== $v rc=$? (non-zero = the budgets caught it)"
-    grep -E "PARITY_MEASURE|passed|failed" $O/pytest_$v.log | sort | uniq | tail -30
+    timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_$v.log 2>&1; echo "== $v rc=$? (non-zero = the budgets caught it)"
+    grep -E "^FAILED|passed|failed" $O/pytest_$v.log | cut -c1-260 | tail -40
   done 2>&1 | tee $O/degraded.log
   cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so
-  timeout 1200 python -m pytest $SUBSET -q -m gpu > $O/pytest_real_vs_budget.log 2>&1; echo "real build vs recorded budget rc=$?" | tee -a $O/degraded.log; tail -2 $O/pytest_real_vs_budget.log ;;
+  timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_real_vs_budget.log 2>&1; echo "real build vs recorded budget rc=$?" | tee -a $O/degraded.log; tail -2 $O/pytest_real_vs_budget.log | tee -a $O/degraded.log ;;
 e2e)
   SECONDS=0; timeout 1500 python tests/e2e_parity.py --frames 16 --steps 20 --out $O/e2e_parity.json > $O/e2e.log 2>&1; echo "e2e rc=$? wall ${SECONDS}s"; grep -v "^{" $O/e2e.log | tail -5
   python -c "import json; d=json.load(open('$O/e2e_parity.json')); print({k: (v['rel_l2'], v['cosine']) for k, v in d.items() if isinstance(v, dict) and 'rel_l2' in v})" ;;
@@ -76,6 +78,11 @@ ab)
     MD_BENCH_DUMP=$O/shapes_${v}_$r.txt timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc 2>/dev/null > $O/ab_${v}_$r.json; echo "== $v (round $r)"; summ $O/ab_${v}_$r.json
   done; done 2>&1 | tee $O/ab.log
   cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so ;;
+trace)
+  cp mikudance_amd/libmdance_hip.so /tmp/lib_keep.so
+  timeout 300 python tools/sp_trace.py ${MD_TRACE:-k640 n1280 ffout} > $O/sp_trace.log 2>&1; echo "trace rc=$?"
+  cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so
+  grep -E "^==|median" $O/sp_trace.log ;;
 *) echo "unknown step $step" ;;
 esac
 done
