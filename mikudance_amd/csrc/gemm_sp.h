@@ -87,10 +87,26 @@ struct SpColumn {
   half4_t a[RA ? MT : 1][4];             // row-broadcast term
 };
 
-template <int MT, int NT, bool RES, bool RA, bool AGPR = true, bool RB = false>
+// Residual look-ahead (round 6).  The residual is the one epilogue operand that comes from far away (the hidden state of the previous
+// layer: HBM or the memory-side cache), and with one wave per SIMD nobody else covers its latency: tools/sp_trace.py prices the epilogue
+// of a 192 x 320 tile WITH residual at 23-35 k cycles (N = K = 1280 / FF-out / N = K = 640: 9-14 K tiles' worth) against ~8-11 k without.
+// LA columns are requested ahead instead of one wherever the tile's register budget allows (the 256 architectural VGPRs hold the main
+// loop's fragments and offsets across the epilogue: 192 x 320 has 14 to spare, 192 x 256 ~40, 128 x 256 ~78).
+#ifndef SP_EPI_LA
+#define SP_EPI_LA 0            // 0: by tile (below); n: pin the residual look-ahead (A/B builds)
+#endif
+template <int MT, int NT, bool CONV>
+constexpr int sp_residual_lookahead() {
+  if (SP_EPI_LA > 0) return SP_EPI_LA < NT - 1 ? SP_EPI_LA : NT - 1;
+  if (MT * NT >= 15) return CONV ? 1 : 2;          // 192 x 320: the conv flavour's tap offsets leave no room for a third column set
+  return MT == 3 && NT == 4 ? 2 : (MT * NT <= 8 ? (NT - 1 < 3 ? NT - 1 : 3) : 1);
+}
+
+template <int MT, int NT, bool RES, bool RA, bool AGPR = true, bool RB = false, bool CONV = false>
 __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][NT], int mw, int nw, int lc, int hi) {
   // RB: the bias belongs to the output ROW (the launcher swapped the operands to produce a transposed output: V^T for attention)
   constexpr bool RA_AHEAD = RA && !RES;
+  constexpr int LA = RES ? sp_residual_lookahead<MT, NT, CONV>() : 1;      // columns requested ahead of the one being written
   const half_t* bias = (p.bias && !RB ? p.bias : g_zero_cols) + (RB ? 0 : nw + 4 * hi);
   float rowb[MT];
   bool row_ok[MT];
@@ -107,7 +123,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
     arow[i] = RA ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra + nw + 4 * hi : nullptr;
     crow[i] = p.C + (size_t)mc * p.ldc + nw + 8 * hi;
   }
-  SpColumn<MT, NT, RES, RA> col[2];
+  SpColumn<MT, NT, RES, RA> col[LA + 1];
   auto request = [&](SpColumn<MT, NT, RES, RA>& d, int j, bool ahead) {
     if constexpr (!RB) {
 #pragma unroll
@@ -128,11 +144,12 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
       }
     }
   };
-  request(col[0], 0, true);
+#pragma unroll
+  for (int j = 0; j < LA && j < NT; ++j) request(col[j % (LA + 1)], j, true);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    SpColumn<MT, NT, RES, RA>& c = col[j & 1];
-    if (j + 1 < NT) request(col[(j + 1) & 1], j + 1, true);
+    SpColumn<MT, NT, RES, RA>& c = col[j % (LA + 1)];
+    if (j + LA < NT) request(col[(j + LA) % (LA + 1)], j + LA, true);
     if constexpr (RA && !RA_AHEAD) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -507,8 +524,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         // the bias is always added (absent: a page of zeros); residual and row-broadcast operand split the code (uniform branches)
         const int mw = m0 + wm * (32 * MT), nw = n0 + wn * (32 * NT);
         if (p.bias_rows) sp_plain_epilogue<MT, NT, false, false, true, true>(p, acc, mw, nw, lc, hi);
-        else if (p.residual && p.rowadd) sp_plain_epilogue<MT, NT, true, true>(p, acc, mw, nw, lc, hi);
-        else if (p.residual) sp_plain_epilogue<MT, NT, true, false>(p, acc, mw, nw, lc, hi);
+        else if (p.residual && p.rowadd) sp_plain_epilogue<MT, NT, true, true, true, false, CONV>(p, acc, mw, nw, lc, hi);
+        else if (p.residual) sp_plain_epilogue<MT, NT, true, false, true, false, CONV>(p, acc, mw, nw, lc, hi);
         else if (p.rowadd) sp_plain_epilogue<MT, NT, false, true>(p, acc, mw, nw, lc, hi);
         else sp_plain_epilogue<MT, NT, false, false>(p, acc, mw, nw, lc, hi);
       }

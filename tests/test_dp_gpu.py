@@ -109,3 +109,72 @@ def test_two_ranks_real_denoise_each_rank_vs_oracle():
                 assert r < 3e-2 and c > 0.999, res
             assert res["distinct"] > 0.1, res                          # the two ranks really worked on different clips
     assert len(results) == world and all(p.exitcode == 0 for p in procs)
+
+
+# ---- window-level parallelism of ONE clip with the real kernels (mikudance_amd/dp.py WindowParallel) ----
+def _wp_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MD_DIST_BACKEND="gloo")
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 2) // world)))
+        import torch.distributed as dist
+        from mikudance_amd import DDIMScheduler, MikuDanceVideoPipeline, dp
+        from mikudance_amd.selftest import SCHED_KWARGS, build_models, cosine, rel_l2
+        from mikudance_amd.synth import synth_inputs
+        dp.init()
+        dev = torch.device("cuda", 0)
+        ref, den, ref_sd, den_sd = build_models(device=dev)
+        pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
+        lat, rl, emb = (t.half().to(dev) for t in synth_inputs(16, 16, 16, ctx_len=5, ctx_dim=64, seed=77))
+        kw = dict(context_frames=8, context_stride=1, context_overlap=2)          # 3 windows, the last one wrapping
+        out = pipe.denoise(lat, rl, emb, 3, GUIDANCE, window_parallel=dp.WindowParallel(), **kw)
+        torch.cuda.synchronize()
+        got = dp.gather_latents(out)
+        res = {"rank": rank}
+        if rank == 0:
+            from oracle import cpu_ref as O                               # checker only
+            one = pipe.denoise(lat, rl, emb, 3, GUIDANCE, **kw)           # all three windows on this rank
+            with torch.no_grad():
+                want = O.denoise_loop(ref_sd, den_sd, lat.float().cpu(), rl.float().cpu(), emb.float().cpu(), 3, guidance_scale=GUIDANCE, reduced=True, **kw)
+            res.update(same_on_both_ranks=torch.equal(got[0], got[1]), equals_one_rank=torch.equal(out, one),
+                       vs_oracle=(rel_l2(out.float(), want), cosine(out.float(), want)))
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{e!r}\n{traceback.format_exc()}"})
+
+
+def test_window_parallel_two_ranks_real_kernels():
+    """Two ranks share cuda:0 (gloo): rank 0 evaluates windows 0 and 2 of every step, rank 1 window 1; one all_reduce of the fp32 accumulators
+    per step.  Every frame lies in at most two windows, so the sums are commutative: both ranks hold the SAME latents, bit-identical to the
+    one-rank loop, and within SURVEY 8c's tolerance of the oracle."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        for _ in range(world):
+            res = q.get(timeout=900)
+            results.append(res)
+            if "error" in res:
+                break
+        for p in procs:
+            if not any("error" in r for r in results):
+                p.join(timeout=120)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    for res in results:
+        assert "error" not in res, res["error"]
+        if res["rank"] == 0:
+            assert res["same_on_both_ranks"] and res["equals_one_rank"], res
+            r, c = res["vs_oracle"]
+            assert r < 3e-2 and c > 0.999, res
+    assert len(results) == world and all(p.exitcode == 0 for p in procs)

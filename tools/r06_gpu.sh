@@ -80,9 +80,9 @@ ab)
   cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so ;;
 trace)
   cp mikudance_amd/libmdance_hip.so /tmp/lib_keep.so
-  timeout 300 python tools/sp_trace.py ${MD_TRACE:-k640 n1280 ffout} > $O/sp_trace.log 2>&1; echo "trace rc=$?"
+  SP_TRACE_LIB=${SP_TRACE_LIB:-trace} timeout 300 python tools/sp_trace.py ${MD_TRACE:-k640 n1280 ffout} > $O/sp_trace.log 2>&1; echo "trace rc=$?"
   cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so
-  grep -E "^==|median" $O/sp_trace.log ;;
+  grep -E "^==|median" $O/sp_trace.log; awk '{ for (i = 6; i <= NF; i += 7) if ($i + 0 > 5000 && $i + 0 < 100000) printf "%s kt %s: step0 + epilogue = %s cycles\n", FILENAME, $2, $i }' $O/sp_trace.log | head -12 ;;
 *) echo "unknown step $step" ;;
 esac
 done

@@ -23,13 +23,13 @@ for what in sys.argv[1:] or ["conv", "gemm", "gemm_res"]:
         a = torch.randn(M, K, device=dev).half(); w = (torch.randn(Nn, K, device=dev) * K ** -0.5).half()
         r = torch.randn(M, Nn, device=dev).half(); b = torch.randn(Nn, device=dev).half()
         fn = lambda: ops.gemm(a, w, bias=b, residual=r)
-    elif what in ("ffout", "n1280", "k640"):
+    elif what in ("ffout", "n1280", "k640", "n1280_nores"):
         # round 6: the GEMM-tail shapes of VERDICT r05 item 3, with their epilogues (bias + residual): FeedForward's output projection
         # (A streamed once from HBM, 20 K tiles per output tile), the 24 x 24 level's N = K = 1280 projections, the 48 x 48 level's N = K = 640
-        M, Nn, K = {"ffout": (294912, 320, 1280), "n1280": (18432, 1280, 1280), "k640": (73728, 640, 640)}[what]
+        M, Nn, K = {"ffout": (294912, 320, 1280), "n1280": (18432, 1280, 1280), "k640": (73728, 640, 640), "n1280_nores": (18432, 1280, 1280)}[what]
         a = torch.randn(M, K, device=dev).half(); w = (torch.randn(Nn, K, device=dev) * K ** -0.5).half()
         r = torch.randn(M, Nn, device=dev).half(); b = torch.randn(Nn, device=dev).half()
-        fn = lambda: ops.gemm(a, w, bias=b, residual=r)
+        fn = (lambda: ops.gemm(a, w, bias=b)) if what.endswith("_nores") else (lambda: ops.gemm(a, w, bias=b, residual=r))
     else:
         x = torch.randn(32, 96, 96, 320, device=dev).half(); w = (torch.randn(320, 9 * 320, device=dev) * 0.02).half()
         fn = lambda: ops.conv3x3(x, w, 320)
