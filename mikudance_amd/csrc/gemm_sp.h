@@ -87,19 +87,22 @@ struct SpColumn {
   half4_t a[RA ? MT : 1][4];             // row-broadcast term
 };
 
-// Residual look-ahead (round 6).  The residual is the one epilogue operand that comes from far away (the hidden state of the previous
-// layer: HBM or the memory-side cache), and with one wave per SIMD nobody else covers its latency: tools/sp_trace.py prices the epilogue
-// of a 192 x 320 tile WITH residual at 23-35 k cycles (N = K = 1280 / FF-out / N = K = 640: 9-14 K tiles' worth) against ~8-11 k without.
-// LA columns are requested ahead instead of one wherever the tile's register budget allows (the 256 architectural VGPRs hold the main
-// loop's fragments and offsets across the epilogue: 192 x 320 has 14 to spare, 192 x 256 ~40, 128 x 256 ~78).
+// Residual look-ahead (round 6): how many columns ahead of the one being written the residual is requested.  ONE, as since round 3 --
+// measured, not assumed: tools/sp_trace.py prices the epilogue of a 192 x 320 tile at ~10 k cycles without and 21-33 k cycles WITH a
+// residual (N = K = 1280: 22 k against a K loop of 51 k; FF-out 27-30 k against 55 k; N = K = 640 31-35 k against 25 k), and two columns
+// ahead (-DSP_EPI_LA=2, all the register file leaves to the 192 x 320 / 192 x 256 tiles; three on 128 x 256) change neither the trace
+// (22.4 -> 21.0 k) nor the clip (7.345 / 7.354 vs 7.352 / 7.350 frames/s): the cost is not latency.  The persistent grid runs its rounds
+// in lock step, so all 256 CUs reach their epilogues together and move 2 x 31 MB (residual in, result out) in one burst: 63 MB in
+// ~11 us = the fabric's ~5.7 TB/s, while during the K loops the fabric idles (profiles/r06_sp_trace_gemm_tail.log,
+// profiles/r06_ab_sp_residual_lookahead.log).  What would help is traffic SPREAD over the K loop (residual pulled into L2 by dummy DMA
+// pieces in the last K tiles) or desynchronised CUs -- priced in profiles/HISTORY.md, not built.
 #ifndef SP_EPI_LA
-#define SP_EPI_LA 0            // 0: by tile (below); n: pin the residual look-ahead (A/B builds)
+#define SP_EPI_LA 1            // A/B builds: -DSP_EPI_LA=n
 #endif
 template <int MT, int NT, bool CONV>
 constexpr int sp_residual_lookahead() {
-  if (SP_EPI_LA > 0) return SP_EPI_LA < NT - 1 ? SP_EPI_LA : NT - 1;
-  if (MT * NT >= 15) return CONV ? 1 : 2;          // 192 x 320: the conv flavour's tap offsets leave no room for a third column set
-  return MT == 3 && NT == 4 ? 2 : (MT * NT <= 8 ? (NT - 1 < 3 ? NT - 1 : 3) : 1);
+  constexpr int la = SP_EPI_LA < NT - 1 ? SP_EPI_LA : NT - 1;
+  return CONV && MT * NT >= 15 && la > 1 ? 1 : la;      // 192 x 320 conv: the tap offsets leave no room for a third column set
 }
 
 template <int MT, int NT, bool RES, bool RA, bool AGPR = true, bool RB = false, bool CONV = false>
