@@ -47,7 +47,7 @@
 #ifdef SP_TRACE
 // diagnostic build only (tools/build_ab.sh trace -DSP_TRACE, tools/sp_trace.py): shader-clock stamps of workgroup 0, every wave, its
 // first SP_TRACE_N K tiles; kept in the LDS left over by the ring and copied out when the kernel ends
-#define SP_TRACE_N 40
+#define SP_TRACE_N 48
 __device__ unsigned long long g_sp_trace[4][SP_TRACE_N][5];
 #define SP_STAMP(S)                                                                                           \
   if (!GEGLU && blockIdx.x == 0 && tr_kt < SP_TRACE_N && lane == 0)                                           \
@@ -88,14 +88,16 @@ struct SpColumn {
 };
 
 // Residual look-ahead (round 6): how many columns ahead of the one being written the residual is requested.  ONE, as since round 3 --
-// measured, not assumed: tools/sp_trace.py prices the epilogue of a 192 x 320 tile at ~10 k cycles without and 21-33 k cycles WITH a
-// residual (N = K = 1280: 22 k against a K loop of 51 k; FF-out 27-30 k against 55 k; N = K = 640 31-35 k against 25 k), and two columns
-// ahead (-DSP_EPI_LA=2, all the register file leaves to the 192 x 320 / 192 x 256 tiles; three on 128 x 256) change neither the trace
-// (22.4 -> 21.0 k) nor the clip (7.345 / 7.354 vs 7.352 / 7.350 frames/s): the cost is not latency.  The persistent grid runs its rounds
-// in lock step, so all 256 CUs reach their epilogues together and move 2 x 31 MB (residual in, result out) in one burst: 63 MB in
-// ~11 us = the fabric's ~5.7 TB/s, while during the K loops the fabric idles (profiles/r06_sp_trace_gemm_tail.log,
-// profiles/r06_ab_sp_residual_lookahead.log).  What would help is traffic SPREAD over the K loop (residual pulled into L2 by dummy DMA
-// pieces in the last K tiles) or desynchronised CUs -- priced in profiles/HISTORY.md, not built.
+// measured, not assumed.  tools/sp_trace.py prices the epilogue of a 192 x 320 tile at ~10 k cycles without and 21-33 k cycles WITH a
+// residual (N = K = 1280: 21 k against a K loop of 51 k; FF-out 27-31 k against 55 k; N = K = 640 31-35 k against 25 k:
+// profiles/r06_sp_trace_gemm_tail.log).  Ablation builds (profiles/r06_sp_epilogue_ablation.log): the stores alone cost ~10 k, the residual
+// loads alone 12-15 k, together their SUM -- a wave's vector-memory operations complete in order on one counter, so the next column's
+// residual loads return only after the previous column's stores have been acknowledged, and under the lock-step burst of 256 CUs storing
+// at once that takes thousands of cycles.  Hence neither two / three columns of look-ahead (-DSP_EPI_LA=2 / 3: 22.4 -> 21.0 k in the
+// trace, 7.345 / 7.354 vs 7.352 / 7.350 frames/s: profiles/r06_ab_sp_residual_lookahead.log) nor pulling the residual into L2 with
+// extra DMA pieces at the end of the K loop (-0.3 % end to end: profiles/r06_ab_sp_residual_prefetch.log) changes anything.  What would
+// (all residual loads of a tile ahead of its first store; the residual injected through the matrix core as extra K tiles) is priced in
+// profiles/HISTORY.md, not built.
 #ifndef SP_EPI_LA
 #define SP_EPI_LA 1            // A/B builds: -DSP_EPI_LA=n
 #endif
@@ -210,31 +212,11 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
   }
 }
 
-// Residual prefetch (RESP, round 6).  tools/sp_trace.py: the epilogue of a tile WITH a residual costs 21-35 k cycles against ~10 k without
-// (profiles/r06_sp_trace_gemm_tail.log) -- and not because of latency (requesting two or three columns ahead changes nothing:
-// profiles/r06_ab_sp_residual_lookahead.log).  The persistent grid runs its rounds in lock step: all 256 CUs reach their epilogues
-// together and pull 256 x 123 KB of residual through the fabric in one burst while writing as much, and during the K loops the fabric
-// idles.  RESP spreads the read half of that burst over the end of the K loop: in the last PFK K tiles of every output tile each wave
-// issues PFX extra DMA pieces (8 rows x one 128-byte line each, `buffer_load ... lds` into a 1-KiB sink nobody reads) that walk the
-// tile's residual block, so that the epilogue's own loads hit the XCD's L2.  Nothing depends on the prefetched bytes; the pieces are
-// counted (vmcnt(PA + PFX) behind a prefetching K tile) like every other piece of the ring.  Launcher: residual present, M % BM == 0
-// (every address in bounds by construction: the scalar part of a buffer address is not range-checked).
-template <int MT, int NT>
-struct SpPrefetch {
-  static constexpr int MF = MT * NT;                                   // MFMAs per k-step
-  static constexpr int PFX = MF >= 12 ? 3 : (MF >= 8 ? 2 : 1);         // extra pieces per wave in a prefetching K tile
-  static constexpr int PFW = (64 * MT / 8) * NT / 4;                   // pieces per wave that cover the tile: (rows / 8) x (lines per row) / 4 waves
-  static constexpr int PFK = (PFW + PFX - 1) / PFX;                    // K tiles (at the end of an output tile's K loop) that prefetch
-};
-
-template <bool CONV, bool GEGLU, int MT, int NT, bool RESP = false>
+template <bool CONV, bool GEGLU, int MT, int NT>
 __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub: it cannot lower the buffer-descriptor type used below
   constexpr int BK = 64;
   constexpr int BM = 64 * MT, BN = 64 * NT;
-  static_assert(!RESP || !GEGLU, "GEGLU has no residual");
-  using PFC = SpPrefetch<MT, NT>;
-  constexpr int PFX = RESP ? PFC::PFX : 0;
   constexpr int ROWB = BK * 2, RPI = 1024 / ROWB;        // 128-byte rows, 8 rows per DMA piece
   constexpr int PA = BM / RPI / 4, PB = BN / RPI / 4;   // DMA pieces per wave per K tile: A rows (6 / 8), W rows (10 / 8)
   // issue schedule of a wave's PA + PB pieces per K tile over the four k-steps that follow the tile's barrier, W pieces first:
@@ -245,11 +227,6 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   static_assert(NP0 + NP1 + NP2 + NP3 == PA + PB && PB >= NP0, "issue schedule");
   static_assert(!GEGLU || NT % 2 == 0, "GEGLU pairs 32-column sub-tiles (2q, 2q+1) of a wave");
   constexpr int ASZ = BM * ROWB, WSZ = BN * ROWB, WBASE = 3 * ASZ;        // ring: A slots 0..2, then W slots 0..1
-#ifdef SP_TRACE
-  constexpr int SP_SINK = (3 * BM + 2 * BN) * 128 + (GEGLU ? 0 : 4 * SP_TRACE_N * 5 * 8);   // behind the stamps
-#else
-  constexpr int SP_SINK = (3 * BM + 2 * BN) * 128;                         // RESP: 1 KiB behind the ring that the prefetch pieces land in (never read)
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -287,9 +264,6 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   // per piece.  Lanes whose tap falls outside the image get an offset beyond the descriptor's range: the load returns zeros.
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A), 0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.W), 0, 0x80000000u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(RESP ? p.residual : p.A), 0, 0x80000000u, 0x00020000);
-  const unsigned pf_voff = ((unsigned)(lane >> 3) * (unsigned)p.ldr + (unsigned)(lane & 7) * 8u) * 2u;   // 8 rows x one 128-byte line
-  int pf_m0 = 0, pf_n0 = 0, pf_kt = 0;             // origin of the output tile being multiplied; its K tile (scalars)
   constexpr unsigned OOB = 0x80000000u;            // >= num_records for every scalar offset < 2^31 (no 32-bit wrap)
   unsigned a_voff[PA], w_voff[PB];                 // per-lane byte offsets of this wave's pieces
   int a_oy[PA], a_ox[PA];                          // conv: input row / column of filter tap (0, 0) of the lane's output pixel
@@ -381,25 +355,13 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
     }
   };
   // piece q = 0..15 of the list [W pieces 0..PB-1 | A pieces 0..PA-1]; each stream moves on behind its last piece
-  // prefetch piece x = 0 .. PFX-1 of K tile pf_kt: piece i of this wave's PFW, i counted from the first prefetching K tile (nk - PFK)
-  auto issue_pf = [&](int x) {
-    const int first = nk > PFC::PFK ? nk - PFC::PFK : 1;
-    int i = (pf_kt - first) * PFX + x;
-    i = i < PFC::PFW ? i : PFC::PFW - 1;
-    const int pc = wave * PFC::PFW + i;
-    const int rg = pc / NT, g = pc - rg * NT;       // 8-row group, 128-byte line of the tile's residual block
-    const unsigned soff = ((unsigned)(pf_m0 + 8 * rg) * (unsigned)p.ldr + (unsigned)(pf_n0 + 64 * g)) * 2u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (lptr_t)(smem + SP_SINK), 16, pf_voff, soff, 0, 0);
-  };
   auto issue_q = [&](int q) {
     if (q < PB) {
       issue_w(q < PB ? q : 0);
       if (q == PB - 1) advance_w();
-    } else if (q < PB + PA) {
+    } else {
       issue_a(q < PB ? 0 : q - PB);
       if (q == PB + PA - 1) advance_a();
-    } else {
-      issue_pf(q - PB - PA);
     }
   };
 
@@ -440,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                  \
       }                                                                                                     \
       if (!(SP_ABL & 2)) {                                                                                  \
-        constexpr int STRIDE = ((NP) == 6 || (NP) == 5) ? 2 : ((NP) == 4 ? (MT * NT >= 12 ? 3 : 2) : ((NP) == 3 ? (MT * NT >= 8 ? 4 : 2) : (MT * NT >= 12 ? 6 : (MT * NT >= 8 ? 4 : 3)))); \
+        constexpr int STRIDE = (NP) == 6 ? 2 : ((NP) == 4 ? (MT * NT >= 12 ? 3 : 2) : ((NP) == 3 ? (MT * NT >= 8 ? 4 : 2) : (MT * NT >= 12 ? 6 : (MT * NT >= 8 ? 4 : 3)))); \
         static_assert(STRIDE * ((NP) - 1) + 1 < MT * NT, "a DMA piece per MFMA gap at most");               \
         if (k % STRIDE == 1 && k / STRIDE < (NP)) {                                                         \
           issue_q((Q0) + k / STRIDE);                                                                       \
@@ -475,17 +437,17 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   // The first K tile is PEELED out of the K loop instead of being selected inside it: a select would merge two definitions of
   // every accumulator at one program point, and the register allocator then shuffles the 240 accumulators through VGPRs and
   // scratch on every iteration.
-#define SP_BODY(ZERO, PF)                                                                                   \
+#define SP_BODY(ZERO)                                                                                       \
   {                                                                                                         \
     SP_STAMP(0)                                                                                             \
     SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, NP0, NP1)                                                  \
     SP_STAMP(1)                                                                                             \
     SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, NP0 + NP1, NP2)                                           \
     SP_STAMP(2)                                                                                             \
-    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, NP0 + NP1 + NP2, NP3 + (PF)) /* + the residual prefetch pieces, last in the list */ \
+    SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, NP0 + NP1 + NP2, NP3)                                     \
     SP_STAMP(3)                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    if (!(SP_ABL & 8)) wait_vmcnt<PA + (PF)>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) (and prefetch) pieces may fly */ \
+    if (!(SP_ABL & 8)) wait_vmcnt<PA>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
     if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier();                                                        \
     SP_STAMP(4)                                                                                             \
     ca += ASZ;                                                                                              \
@@ -504,25 +466,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #endif
 #pragma unroll 1
   for (int ct = 0; ct < ntile; ++ct) {
-    if constexpr (RESP) {
-      // two loops one after the other, NOT a branch around two bodies inside one loop: a join of two definitions of every accumulator
-      // sends the register allocator through scratch (the same reason the first K tile is peeled)
-      tile_origin(ct, pf_m0, pf_n0);
-      const int pf_from = nk > PFC::PFK ? nk - PFC::PFK : 1;           // the last PFK K tiles of the output tile prefetch its residual
-      SP_BODY(true, 0)                                                 // (the peeled first K tile never does: short K loops lose one)
-      int kt = 1;
+    SP_BODY(true)
 #pragma unroll 1
-      for (; kt < pf_from; ++kt) SP_BODY(false, 0)
-#pragma unroll 1
-      for (; kt < nk; ++kt) {
-        pf_kt = kt;
-        SP_BODY(false, PFX)
-      }
-    } else {
-      SP_BODY(true, 0)
-#pragma unroll 1
-      for (int kt = 1; kt < nk; ++kt) SP_BODY(false, 0)
-    }
+    for (int kt = 1; kt < nk; ++kt) SP_BODY(false)
     {
       // ---- epilogue of output tile ct, straight from the accumulators
       int m0, n0;
@@ -624,23 +570,16 @@ static bool sp_eligible(const GemmParams& p) {
   return true;
 }
 
-template <bool CONV, bool GEGLU, int NT, int MT, bool RESP>
-static void launch_sp_variant(GemmParams& p, hipStream_t stream, int grid) {
-  constexpr int BM = 64 * MT, BN = 64 * NT;
-#ifdef SP_TRACE
-  constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128 + (GEGLU ? 0 : 4 * SP_TRACE_N * 5 * 8) + (RESP ? 1024 : 0);
-  static_assert(smem <= 160 * 1024, "trace build: the stamps (and the prefetch sink) live behind the ring");
-#else
-  constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128 + (RESP ? 1024 : 0);   // A ring of three, W ring of two 64-deep K tiles (+ the prefetch sink)
-  static_assert(smem <= 160 * 1024, "LDS");
-#endif
-  md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT, RESP>>((int)smem);
-  hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT, RESP>), dim3(grid), dim3(256), smem, stream, p);
-}
-
 template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5, int MT = GEGLU ? 4 : 3>
 static void launch_sp(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
+#ifdef SP_TRACE
+  constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128 + (GEGLU ? 0 : 4 * SP_TRACE_N * 5 * 8);
+  static_assert(smem <= 160 * 1024, "trace build: the stamps live behind the ring");
+#else
+  constexpr size_t smem = (size_t)(3 * BM + 2 * BN) * 128;          // A ring of three, W ring of two 64-deep K tiles
+#endif
+  md_ensure_dynamic_lds<gemm_sp_kernel<CONV, GEGLU, MT, NT>>((int)smem);
   constexpr int group_m = 8;       // row-major order (1) measured 3-38 % slower on the wide-N shapes (profiles/r03_ab_gemm_sp.log)
   p.tiles_n = p.N / BN;
   p.tiles_m = cdiv(p.M, BM);
@@ -656,15 +595,7 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   p.reverse = !CONV && !GEGLU && !p.bias_rows && big_a && (rev == 2 || (rev == 1 && p.K >= 4 * p.N));
   const int ncu = md_device_cus();
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
-  // residual prefetch (gemm_sp_kernel RESP): whole tiles only (every prefetch address in bounds by construction), residual block within
-  // the 2^31-byte reach of a buffer descriptor.  MD_SP_PF = 0 switches it off (A/B); 1 (default) on wherever eligible.
-  if constexpr (!GEGLU) {
-    static const int pf = md_env_int("MD_SP_PF", 1);
-    const bool resp = pf && p.residual && !p.bias_rows && p.M % BM == 0 && p.ldr % 8 == 0 &&
-                      ((unsigned long long)(p.M - 1) * p.ldr + p.N) * 2 < (1ull << 31);
-    if (resp) return launch_sp_variant<CONV, GEGLU, NT, MT, true>(p, stream, grid);
-  }
-  launch_sp_variant<CONV, GEGLU, NT, MT, false>(p, stream, grid);
+  hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);
 }
 
 #ifdef SP_TRACE
