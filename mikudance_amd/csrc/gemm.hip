@@ -580,6 +580,15 @@ static int md_device_cus() {
 #include "gemm_ws.h"
 #include "gemm_sp.h"
 
+// Row streams of a streaming launch with G = p.groups column groups: spx per XCD on G spx of its 32 CUs, plus the extra streams that the
+// 8 (32 - G spx) leftover CUs of the chip can form (gemm_ws.h).  MD_WS_EXTRA = 0 leaves them idle as until round 5 (A/B).
+static void ws_streams(WsParams& p) {
+  static const int extra = md_env_int("MD_WS_EXTRA", 1);
+  p.spx = 32 / p.groups;
+  p.xstreams = extra ? 8 * (32 - p.groups * p.spx) / p.groups : 0;
+  p.streams = 8 * p.spx + p.xstreams;
+}
+
 template <int KS, int CB, int TPR, bool RES, bool RA>
 static void launch_ws_variant(const WsParams& p, hipStream_t stream) {
   using Cfg = WsCfg<KS, CB, TPR>;
@@ -602,8 +611,7 @@ static void launch_ws(const GemmParams& g, hipStream_t stream) {
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = g.residual; p.rowadd = g.rowadd;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr; p.ldra = g.ldra; p.M = g.M; p.N = g.N; p.rows_per_group = g.rows_per_group;
   p.groups = g.N / GC;
-  p.spx = 32 / p.groups;
-  p.streams = 8 * p.spx;
+  ws_streams(p);
   // one tile per barrier round (deepest DMA ring) when the launch streams A from HBM once and sits on the store path (one column
   // group); two tiles per round when several groups share A through L2 and the tile time is barrier / latency bound
   if (p.groups > 1) launch_ws_tpr<KS, CB, 2>(p, stream);
@@ -623,8 +631,7 @@ static void launch_ws_geglu(const GemmParams& g, hipStream_t stream) {
   p.A = g.A; p.W = g.W; p.C = g.C; p.bias = g.bias; p.residual = nullptr; p.rowadd = nullptr;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = 0; p.ldra = 0; p.M = g.M; p.N = g.N; p.rows_per_group = 1;
   p.groups = g.N / 256;
-  p.spx = 32 / p.groups;
-  p.streams = 8 * p.spx;
+  ws_streams(p);
   // the GELU arithmetic (shared by the four memory waves), not the barrier rounds, bounds a GEGLU tile: one tile per round
   constexpr int smem = WsCfg<10, 4, 1>::SMEM;
   md_ensure_dynamic_lds<wsgemm_kernel<10, 4, 1, false, false, true>>(smem);
@@ -662,7 +669,7 @@ extern "C" int md_gemm_ln_f16(const void* A, int lda, const void* Wf, const floa
   p.A = (const half_t*)A; p.W = (const half_t*)Wf; p.C = (half_t*)C; p.rowadd = (const half_t*)rowadd;
   p.lda = lda; p.ldc = ldc; p.ldra = ldra; p.M = M; p.N = N; p.rows_per_group = rowadd ? rows_per_group : 1;
   p.lnf = sc; p.eps = eps;
-  p.groups = N / 320; p.spx = 32 / p.groups; p.streams = 8 * p.spx;
+  p.groups = N / 320; ws_streams(p);
   hipStream_t st = (hipStream_t)stream;
   if (p.groups > 1) {
     if (rowadd) launch_ws_fused<2, true, PRO_LNF>(p, st);
@@ -689,7 +696,7 @@ extern "C" int md_gemm_affine_f16(const void* A, int lda, const float* table, in
   p.A = (const half_t*)A; p.W = (const half_t*)W; p.C = (half_t*)C; p.bias = (const half_t*)bias;
   p.lda = lda; p.ldc = ldc; p.M = M; p.N = N; p.rows_per_group = 1;
   p.aff = table; p.rows_per_image = rows_per_image;
-  p.groups = N / 320; p.spx = 32 / p.groups; p.streams = 8 * p.spx;
+  p.groups = N / 320; ws_streams(p);
   hipStream_t st = (hipStream_t)stream;
   if (p.groups > 1) launch_ws_fused<2, false, PRO_AFF>(p, st);
   else launch_ws_fused<1, false, PRO_AFF>(p, st);

@@ -57,6 +57,7 @@ struct WsParams {
   int groups;        // column groups G
   int streams;       // row streams (workgroups per column group)
   int spx;           // row streams per XCD
+  int xstreams;      // extra row streams made of the CUs that G column groups x spx streams leave idle on every XCD (round 6, ws_streams)
   // prologue flavours (PRO != 0): a normalisation of the A rows that never exists in HBM
   const float* lnf;  // PRO_LNF: [2][N] fp32 -- s[n] = sum_k W'[n][k] and c[n] = sum_k beta[k] W[n][k] + bias[n] of the folded LayerNorm
   float eps;         // PRO_LNF: LayerNorm epsilon
@@ -174,9 +175,17 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // workgroup -> (XCD, column group, row stream): the G groups of one row stream share an XCD (blockIdx % 8)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int grp = slot % p.groups, sl = slot / p.groups;
-  if (sl >= p.spx) return;
-  const int stream = xcd * p.spx + sl;
+  int grp = slot % p.groups, stream = xcd * p.spx + slot / p.groups;
+  if (slot >= p.groups * p.spx) {
+    // Leftover CUs (round 6).  G groups x spx streams fill G spx of the 32 CUs of an XCD: 30 for G = 5 (K = N = 640), 15 (N = 1920), 3 (N = 960)
+    // and 10 (GEGLU N = 2560) -- two CUs per XCD, 16 on the chip, used to idle.  They are numbered XCD-major (a stream's groups stay on as few
+    // XCDs as possible; their re-reads of the stream's A rows then cross XCDs, a few percent of one stream's bytes) and form xstreams more
+    // row streams of G workgroups each.
+    const int left = 32 - p.groups * p.spx, e = xcd * left + (slot - p.groups * p.spx);
+    if (e >= p.xstreams * p.groups) return;
+    grp = e % p.groups;
+    stream = 8 * p.spx + e / p.groups;
+  }
   const int ntiles = (p.M + TR - 1) / TR;
   // local tile t of this stream is tile tile0 + t * tstep: interleaved (stream, stream + S, ...), or one contiguous block per stream (PRO_AFF)
   const int tps = (ntiles + p.streams - 1) / p.streams;

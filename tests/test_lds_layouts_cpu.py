@@ -204,3 +204,33 @@ def test_wsgemm_contiguous_row_blocks_cover_every_tile_once():
         assert seen == list(range(ntiles))
         if M == 294912:
             assert all((s * tps * 16) // rows_per_image == ((s * tps + tps - 1) * 16) // rows_per_image for s in range(streams))
+
+
+def test_streaming_gemm_workgroup_to_stream_mapping_uses_the_leftover_cus():
+    """wsgemm_kernel's blockIdx -> (row stream, column group) map (gemm_ws.h, round 6): G groups x spx = 32 // G streams per XCD, and the
+    32 - G spx CUs that leaves idle on every XCD form 8 (32 - G spx) // G extra streams (numbered XCD-major).  Every (stream, group) pair is
+    owned by exactly one of the 256 workgroups, the groups of a regular stream share one XCD, an extra stream spans as few XCDs as possible."""
+    for G in (1, 2, 3, 4, 5, 8, 10, 15, 16):
+        spx = 32 // G
+        left = 32 - G * spx
+        xstreams = 8 * left // G
+        streams = 8 * spx + xstreams
+        owner, xcds = {}, {}
+        for b in range(256):
+            xcd, slot = b & 7, b >> 3
+            if slot < G * spx:
+                grp, stream = slot % G, xcd * spx + slot // G
+            else:
+                e = xcd * left + (slot - G * spx)
+                if e >= xstreams * G:
+                    continue
+                grp, stream = e % G, 8 * spx + e // G
+            assert (stream, grp) not in owner
+            owner[(stream, grp)] = b
+            xcds.setdefault(stream, set()).add(xcd)
+        assert len(owner) == streams * G and {s for s, _ in owner} == set(range(streams))
+        assert all(len(xcds[s]) == 1 for s in range(8 * spx))
+        if xstreams:
+            assert max(len(xcds[s]) for s in range(8 * spx, streams)) <= -(-G // left) + 1
+        # G = 5 (K = N = 640): 48 + 3 streams on 255 CUs; G = 10 (GEGLU N = 2560): 24 + 1; G = 3 (N = 960): 80 + 5; G = 15 (N = 1920): 16 + 1
+        assert {1: 256, 2: 128, 3: 85, 4: 64, 5: 51, 8: 32, 10: 25, 15: 17, 16: 16}[G] == streams
