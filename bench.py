@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes behind roofline.traffic (quote profiles/pmc_traffic.json)")
     ap.add_argument("--no-vae", action="store_true", help="skip the AutoencoderKL timing behind the extra keys vae_ms_per_clip / e2e_frames_per_s")
     ap.add_argument("--no-reuse", action="store_true", help="literal reference algorithm: reference UNet at every step on 2f frames")
+    ap.add_argument("--no-share", action="store_true", help="A/B: evaluate conv_in + the first resnet of the denoising UNet on both CFG halves (literal)")
     ap.add_argument("--small", action="store_true", help="reduced-width UNets (debug only; NOT the benchmark)")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 owns the batch and scatters the per-clip conditioning inside "
                     "the timed region (default: every rank stages its own clip before it)")
@@ -102,6 +103,7 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
     ref, den, ref_sd, den_sd = build_models(geom=geom, device=dev, keep_state_dicts=want_cpu)
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     pipe.reference_reuse = not args.no_reuse
+    pipe.share_first_layers = not args.no_share
     h = w = args.size // 8
     setup_s = time.time() - t0
     # the plumbing test (CPU, gloo) replaces the kernels by a stand-in: launch, collectives, timing protocol and the JSON line

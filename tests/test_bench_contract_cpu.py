@@ -180,3 +180,31 @@ def test_round5_line_reports_the_usable_cores_of_its_cpu_baseline():
     labels = " ".join(s["label"] for s in d["top_launch_shapes"])
     assert " ln" in labels and d["kernel_families"]["layernorm"]["ms_per_clip"] < 80 and d["kernel_families"]["groupnorm"]["ms_per_clip"] < 105
     assert 0.0 < d["mfma_frac_whole_loop"] < 1.0 and d["e2e_frames_per_s"] < d["value"] and d["vae_ms_per_clip"] < 310
+
+
+def test_round6_line_carries_the_diagnostics_the_first_multi_gpu_run_needs():
+    d = _record("r06_bench.json")
+    assert "768x768" in d["metric"] and "configs[1]" in d["config"]["workload"] and d["n_gpus"] == d["n_ranks_seen"] == 1 and d["scaling"] == "weak"
+    frames = int(re.search(r"(\d+)f,", d["metric"]).group(1))
+    assert math.isclose(d["value"], frames / (d["ms_per_step"] * 1e-3), rel_tol=1e-6) and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-9) and "measured" in r["traffic_source"]
+    # who computed where: one record per rank with the device's UUID and PCI bus id, its own loop time, the collective library
+    m = d["multi_gpu"]
+    assert len(m["per_rank"]) == 1 and m["n_distinct_gpus"] == 1 and m["gpu_aliasing"] is False
+    me = m["per_rank"][0]
+    assert me["uuid"] and re.match(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.0$", me["pci_bus_id"]) and me["cus"] == 256 and me["hbm_gib"] > 250
+    assert math.isclose(me["own_ms_per_step"], d["ms_per_step"], rel_tol=1e-3) and m["collectives"]["rccl_version"]
+    # the VAE beside the loop, by config: absent face / hand guidance = 2F copies of one black frame, encoded once
+    v = d["vae_by_config"]
+    assert v["configs[1]"]["images"] == v["configs[2]"]["images"] == 3 * frames + 2 and v["configs[1]"]["encoded"] == frames + 3 and v["configs[2]"]["encoded"] == 3 * frames + 2
+    assert v["configs[1]"]["ms"] < 0.7 * v["configs[2]"]["ms"] and d["vae_ms_per_clip"] == v["configs[1]"]["ms"]
+    e = d["e2e_frames_per_s_by_config"]
+    assert e["configs[2]"] < e["configs[1]"] < d["value"] and math.isclose(d["e2e_frames_per_s"], e["configs[1]"])
+    # the CPU baseline shows its extrapolation: one step of 4 frames next to one step of 1 frame; value from the 1-frame step only within 10 %
+    c = d["cpu_baseline"]
+    lin = c["frames_linearity"]
+    assert math.isclose(lin["ratio_to_linear"], lin["s_per_step_4_frames"] / (4 * lin["s_per_step_1_frame"]), rel_tol=2e-2)
+    assert lin["within_10_percent"] == (abs(lin["ratio_to_linear"] - 1) <= 0.10)
+    want = (1.0 / (lin["s_per_step_1_frame"] * 20)) if lin["within_10_percent"] else (4.0 / (lin["s_per_step_4_frames"] * 20))
+    assert math.isclose(c["value"], want, rel_tol=2e-2) and c["cores"] == c["usable_cores"] and c["value"] < d["value"]
