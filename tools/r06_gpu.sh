@@ -11,6 +11,8 @@
 #   kern ARGS     tools/bench_kernels.py with MD_KERN="gemm shapes ..." (30 iterations)
 #   trace         tools/sp_trace.py (needs tools/ab/lib_trace.so) on the shapes in MD_TRACE
 #   ab            same-box end-to-end A/B of the libraries named in MD_AB="base cand" (tools/ab/lib_*.so), two rounds, family table
+#   abenv / abflag / kernenv   same-box A/B of one environment knob (MD_AB_ENV, MD_AB_VALUES) or one bench.py flag (MD_AB_FLAG) in ONE library; the knob on the micro-benchmarks
+#   ranks2 / queues            2-rank runs of bench.py on the one GPU (gloo); the two-queue proxy measurement
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-.}
 O=$R/gpurun_out/$TAG
@@ -83,6 +85,34 @@ trace)
   SP_TRACE_LIB=${SP_TRACE_LIB:-trace} timeout 300 python tools/sp_trace.py ${MD_TRACE:-k640 n1280 ffout} > $O/sp_trace.log 2>&1; echo "trace rc=$?"
   cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so
   grep -E "^==|median" $O/sp_trace.log; awk '{ for (i = 6; i <= NF; i += 7) if ($i + 0 > 5000 && $i + 0 < 100000) printf "%s kt %s: step0 + epilogue = %s cycles\n", FILENAME, $2, $i }' $O/sp_trace.log | head -12 ;;
+abenv)
+  # same-box A/B of ONE environment knob in ONE library: MD_AB_ENV=MD_WS_EXTRA MD_AB_VALUES="0 1" [MD_AB_FLAGS="--no-share"]; two rounds, family table + per-shape dumps
+  for r in 1 2; do for v in ${MD_AB_VALUES:-0 1}; do
+    env ${MD_AB_ENV:-MD_NONE}=$v MD_BENCH_DUMP=$O/shapes_${v}_$r.txt timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc $MD_AB_FLAGS 2>/dev/null > $O/ab_${v}_$r.json
+    echo "== ${MD_AB_ENV}=$v (round $r)"; summ $O/ab_${v}_$r.json
+  done; done 2>&1 | tee $O/ab.log ;;
+abflag)
+  # same-box A/B of a bench.py flag: MD_AB_FLAG="--no-share" (off = the flag given); two rounds
+  for r in 1 2; do for f in "$MD_AB_FLAG" ""; do
+    timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc $f 2>/dev/null > $O/ab.json; echo "== flag '${f:-(none)}' (round $r)"; summ $O/ab.json
+  done; done 2>&1 | tee $O/ab.log ;;
+kernenv)
+  for r in 1 2; do for v in ${MD_AB_VALUES:-0 1}; do echo "== ${MD_AB_ENV}=$v (round $r)"; env ${MD_AB_ENV:-MD_NONE}=$v MD_ITERS=30 MD_WARM=5 timeout 400 python tools/bench_kernels.py ${MD_KERN:-gemm skinny} 2>&1 | grep -v amdgpu | grep -E "gemm|conv|attn|norm|temporal"; done; done > $O/kern.log 2>&1; cat $O/kern.log ;;
+ranks2)
+  # bench.py's multi-rank paths with the REAL kernels on the one GPU a lease has (both ranks on cuda:0, collectives over gloo): clip data-parallel (rank-local and
+  # --scatter) at configs[1], window-parallel at configs[4].  Control-flow records (per-rank diagnostics, collectives timed outside the region), NOT scaling figures.
+  export MD_DIST_BACKEND=gloo
+  r2() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $1 bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-pmc "${@:3}" > $O/$2.json 2> $O/$2.err; echo "$2 rc=$?"; }
+  r2 29511 bench_2rank_dp; r2 29512 bench_2rank_dp_scatter --scatter; r2 29513 bench_cfg4_2rank_window_parallel --config 4 --window-parallel
+  summ $O/bench_2rank_dp.json $O/bench_2rank_dp_scatter.json $O/bench_cfg4_2rank_window_parallel.json ;;
+queues)
+  # one CFG clip / one guidance-free clip / two guidance-free clips from two processes / two CFG clips from two processes (profiles/r06_ab_two_queues.log)
+  export MD_DIST_BACKEND=gloo
+  B="--steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc"
+  timeout 400 python bench.py $B > $O/a.json 2>/dev/null; timeout 400 python bench.py $B --guidance 1.0 > $O/b.json 2>/dev/null
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 $B --guidance 1.0 > $O/c.json 2>/dev/null
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29522 bench.py --gpus 2 $B > $O/d.json 2>/dev/null
+  summ $O/a.json $O/b.json $O/c.json $O/d.json ;;
 *) echo "unknown step $step" ;;
 esac
 done
