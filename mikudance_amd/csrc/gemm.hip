@@ -717,7 +717,8 @@ static bool ws_eligible(const GemmParams& p) {
 
 // Plan codes (returned by dispatch_any; md_gemm_plan / md_conv3x3_plan expose them so that the table is testable without a GPU):
 //   1MN  gemm_sp_kernel with wave tile (MT, NT) = (M, N): 135 = 192 x 320, 134 = 192 x 256, 124 = 128 x 256, 144 = 256 x 256 GEGLU;
-//        +1000 when it runs on swapped operands (transposed output)
+//        +1000 when it runs on swapped operands (transposed output); +2000 when the residual enters through the matrix core (RESM: K tiles >
+//        sub-tiles of the wave tile; gemm_sp.h)
 //   210 / 220 / 230  wsgemm_kernel K = 320 / K = 640 / GEGLU
 //   301 / 302 / 303  gemm_kernel 64-column tiles / 256 x 128 / 128 x 128
 template <bool CONV, bool GEGLU, bool DRY>
@@ -788,7 +789,9 @@ static int dispatch_any(GemmParams& p, hipStream_t stream, const int sp, const i
       else if (nt == 32) launch_sp<CONV, false, 2, 3>(p, stream);
       else launch_sp<CONV, false, 5>(p, stream);
     }
-    return GEGLU ? 144 : (nt == 4 ? 134 : (nt == 2 ? 124 : (nt == 42 ? 142 : (nt == 32 ? 132 : 135))));
+    if constexpr (GEGLU) return 144;
+    const bool resm = nt == 4 ? sp_resm<3, 4>(p) : (nt == 2 ? sp_resm<2, 4>(p) : (nt == 42 ? sp_resm<4, 2>(p) : (nt == 32 ? sp_resm<3, 2>(p) : sp_resm<3, 5>(p))));
+    return (resm ? 2000 : 0) + (nt == 4 ? 134 : (nt == 2 ? 124 : (nt == 42 ? 142 : (nt == 32 ? 132 : 135))));
   };
   if (sp == 1 && nt) return run_sp();
   // 1. HBM-bound short-K projections on long token matrices: W-stationary streaming kernel (gemm_ws.h), plain and GEGLU (K = 320)
@@ -867,7 +870,7 @@ static int sp_row_block_plan(const GemmParams& p, int sp, int force_nt, int ncu,
   GemmParams c = p;
   c.M = *rows;
   const int plan = dispatch_any<false, GEGLU, true>(c, nullptr, sp, force_nt, ncu);
-  return plan / 100 == 1 ? nb : 1;
+  return plan % 1000 / 100 == 1 ? nb : 1;      // 1xx, with or without the +2000 of the residual-through-the-matrix-core flavour
 }
 
 template <bool CONV, bool GEGLU>

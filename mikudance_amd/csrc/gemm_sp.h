@@ -56,6 +56,8 @@ __device__ unsigned long long g_sp_trace[4][SP_TRACE_N][5];
 #define SP_STAMP(S)
 #endif
 
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));      // what the raw buffer load returns
+
 // zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
 __device__ __attribute__((aligned(64))) half_t g_zero_cols[16384] = {};
 
@@ -212,7 +214,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
   }
 }
 
-template <bool CONV, bool GEGLU, int MT, int NT>
+template <bool CONV, bool GEGLU, int MT, int NT, bool RESM = false>
 __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub: it cannot lower the buffer-descriptor type used below
   constexpr int BK = 64;
@@ -384,6 +386,59 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   floatx16 acc[MT][NT];
   half8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
 
+  // ------------------------------------------------------------------ RESM: the residual enters through the matrix core (round 6)
+  // acc = mfma(W, A) holds C^T: D[n][m] += sum_k First[n][k] Second[m][k].  With First = a 32 x 16 slice of the IDENTITY (First[n][k] =
+  // [n == 16 c + k], c = 0, 1) and Second = the residual rows themselves (Second[m][k] = R[m][n0 + 16 c + k]: for lane (frow, fhi) the 16
+  // contiguous bytes R[m = frow][n0 + 16 c + 8 fhi ..+7], ONE buffer_load_dwordx4 straight into the operand registers, no LDS), two MFMAs
+  // add fp32(R) -- exactly: products by 1.0 and by 0.0 -- to a 32 x 32 accumulator sub-tile.  Being an accumulation like any other it can
+  // go ANYWHERE in the K loop: sub-tile u = 0 .. MT NT - 1 of an output tile requests its two pieces in K tile u (behind the last W piece
+  // of the list, at the top of k-step 1) and multiplies them in K tile u + 1 behind the barrier, 1.5 K tiles ~ 3 800 cycles later; two
+  // register generations (u & 1), 16 + 8 + MT registers.  The residual read is thereby spread over the K loop as 2 extra loads per wave and
+  // K tile next to its 10-16 DMA pieces, the epilogue is the bias-only one, and the lock-step burst of 256 CUs all reading their residual
+  // tiles at once (12-25 k cycles per 192 x 320 tile, profiles/r06_sp_epilogue_ablation.log) is gone for MT NT x 2 extra MFMAs per tile
+  // (+2.5 % at K = 1280, +0.4 % on a 3 x 3 conv).  vmcnt: a K tile that requests a residual piece pair lets PA + 2 operations fly over its
+  // barrier (the A pieces and the pair, all younger than every W piece); the pair is older than everything the NEXT barrier lets fly.
+  // In-place (residual == C) stays legal: an output tile reads its residual block before its own epilogue stores, and no other tile's.
+  constexpr int NSUB = MT * NT;
+  [[maybe_unused]] half8_t rid[2];
+  [[maybe_unused]] uint4_t rfr[2][2];
+  [[maybe_unused]] unsigned r_voff[MT];
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_r =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(RESM ? p.residual : p.A), 0, 0x80000000u, 0x00020000);
+  if constexpr (RESM) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rid[c][e] = frow == 16 * c + 8 * fhi + e ? (half_t)1 : (half_t)0;
+  }
+  [[maybe_unused]] auto set_sources_r = [&](int i) {
+    int m0, n0;
+    tile_origin(i, m0, n0);
+#pragma unroll
+    for (int ii = 0; ii < MT; ++ii) {
+      const int m = m0 + wm * (32 * MT) + ii * 32 + frow;
+      const int mm = m < p.M ? m : p.M - 1;
+      r_voff[ii] = ((unsigned)mm * (unsigned)p.ldr + (unsigned)(n0 + wn * (32 * NT) + 8 * fhi)) * 2u;      // < 2^31 (launcher)
+    }
+  };
+  // request the two pieces of sub-tile U (compile-time) / multiply the pieces of sub-tile U
+#define SP_RES_ISSUE(U)                                                                                     \
+  if constexpr ((U) < NSUB) {                                                                               \
+    constexpr int i_ = (U) / NT < MT ? (U) / NT : 0, j_ = (U) % NT, g_ = (U) & 1;                          \
+    rfr[g_][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, r_voff[i_] + j_ * 64, 0, 0);                \
+    rfr[g_][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, r_voff[i_] + j_ * 64 + 32, 0, 0);           \
+  }
+#define SP_RES_MULT(U)                                                                                      \
+  if constexpr ((U) < NSUB) {                                                                               \
+    constexpr int i_ = (U) / NT < MT ? (U) / NT : 0, j_ = (U) % NT, g_ = (U) & 1;                          \
+    half8_t r0_, r1_;                                                                                       \
+    __builtin_memcpy(&r0_, &rfr[g_][0], 16);                                                                \
+    __builtin_memcpy(&r1_, &rfr[g_][1], 16);                                                                \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rid[0], r0_, acc[i_][j_], 0, 0, 0);                \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rid[1], r1_, acc[i_][j_], 0, 0, 0);                \
+  }
+  static_assert(NSUB <= 16, "the peeled K tiles below cover 16 sub-tiles");
+
   // One k-step, issue order pinned by hand (sched_barrier(0) lets nothing cross): MFMA k of the current fragments (FAU, FBU),
   // then -- behind each of the first MT + NT MFMAs -- ONE ds_read_b128 of the next k-step's fragments (FAL, FBL: A slot offset
   // SA, W slot offset SW, k-step S), and NP DMA pieces Q0 .. Q0+NP-1 of the list, evenly spaced.
@@ -437,22 +492,34 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
   // The first K tile is PEELED out of the K loop instead of being selected inside it: a select would merge two definitions of
   // every accumulator at one program point, and the register allocator then shuffles the 240 accumulators through VGPRs and
   // scratch on every iteration.
-#define SP_BODY(ZERO)                                                                                       \
+#define SP_BODY(ZERO, KT)                                                                                   \
   {                                                                                                         \
     SP_STAMP(0)                                                                                             \
     SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 1, ZERO, NP0, NP1)                                                  \
     SP_STAMP(1)                                                                                             \
+    if constexpr (RESM && (KT) < NSUB) {                                                                    \
+      SP_RES_ISSUE(KT)                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }                                                                                                       \
     SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 2, false, NP0 + NP1, NP2)                                           \
     SP_STAMP(2)                                                                                             \
     SP_STEP(fa0, fb0, fa1, fb1, ca, cw, 3, false, NP0 + NP1 + NP2, NP3)                                     \
     SP_STAMP(3)                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    if (!(SP_ABL & 8)) wait_vmcnt<PA>(); /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
+    if (!(SP_ABL & 8)) {                 /* W(t+1), A(t+1) of this wave have landed; its A(t+2) pieces may fly */ \
+      if (RESM && (KT) < NSUB) wait_vmcnt<PA + 2>();   /* ... and the residual pair requested in this K tile */ \
+      else wait_vmcnt<PA>();                                                                                \
+    }                                                                                                       \
     if (!(SP_ABL & 1)) __builtin_amdgcn_s_barrier();                                                        \
     SP_STAMP(4)                                                                                             \
     ca += ASZ;                                                                                              \
     if (ca == 3 * ASZ) ca = 0;                                                                              \
     cw ^= WSZ;                                                                                              \
+    if constexpr (RESM && (KT) >= 1 && (KT) <= NSUB) {                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      SP_RES_MULT((KT) - 1)                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }                                                                                                       \
     SP_STEP(fa1, fb1, fa0, fb0, ca, cw, 0, false, 0, NP0)                                                   \
     SP_TRACE_NEXT                                                                                           \
   }
@@ -466,9 +533,23 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #endif
 #pragma unroll 1
   for (int ct = 0; ct < ntile; ++ct) {
-    SP_BODY(true)
+    if constexpr (RESM) {
+      // the first NSUB + 1 K tiles of an output tile are peeled: K tile u requests sub-tile u's residual pieces, K tile u + 1 multiplies
+      // them, all with compile-time accumulator indices (a runtime switch over the sub-tiles merges 16 definitions of every accumulator
+      // and the register allocator answers with ~800 v_accvgpr_mov per K tile); nk >= NSUB + 1 (launcher)
+      set_sources_r(ct);
+      SP_BODY(true, 0)
+#define SP_PEEL(U) if constexpr ((U) <= NSUB) SP_BODY(false, U)
+      SP_PEEL(1) SP_PEEL(2) SP_PEEL(3) SP_PEEL(4) SP_PEEL(5) SP_PEEL(6) SP_PEEL(7) SP_PEEL(8)
+      SP_PEEL(9) SP_PEEL(10) SP_PEEL(11) SP_PEEL(12) SP_PEEL(13) SP_PEEL(14) SP_PEEL(15) SP_PEEL(16)
+#undef SP_PEEL
 #pragma unroll 1
-    for (int kt = 1; kt < nk; ++kt) SP_BODY(false)
+      for (int kt = NSUB + 1; kt < nk; ++kt) SP_BODY(false, 99)
+    } else {
+      SP_BODY(true, 0)
+#pragma unroll 1
+      for (int kt = 1; kt < nk; ++kt) SP_BODY(false, 99)
+    }
     {
       // ---- epilogue of output tile ct, straight from the accumulators
       int m0, n0;
@@ -528,9 +609,12 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       } else {
         // the bias is always added (absent: a page of zeros); residual and row-broadcast operand split the code (uniform branches)
         const int mw = m0 + wm * (32 * MT), nw = n0 + wn * (32 * NT);
-        if (p.bias_rows) sp_plain_epilogue<MT, NT, false, false, true, true>(p, acc, mw, nw, lc, hi);
-        else if (p.residual && p.rowadd) sp_plain_epilogue<MT, NT, true, true, true, false, CONV>(p, acc, mw, nw, lc, hi);
-        else if (p.residual) sp_plain_epilogue<MT, NT, true, false, true, false, CONV>(p, acc, mw, nw, lc, hi);
+        if constexpr (RESM) {                        // the residual is in the accumulators already
+          if (p.rowadd) sp_plain_epilogue<MT, NT, false, true>(p, acc, mw, nw, lc, hi);
+          else sp_plain_epilogue<MT, NT, false, false>(p, acc, mw, nw, lc, hi);
+        } else if (p.bias_rows) sp_plain_epilogue<MT, NT, false, false, true, true>(p, acc, mw, nw, lc, hi);
+        else if (p.residual && p.rowadd && !(SP_ABL & 32)) sp_plain_epilogue<MT, NT, true, true, true, false, CONV>(p, acc, mw, nw, lc, hi);
+        else if (p.residual && !(SP_ABL & 32)) sp_plain_epilogue<MT, NT, true, false, true, false, CONV>(p, acc, mw, nw, lc, hi);
         else if (p.rowadd) sp_plain_epilogue<MT, NT, false, true>(p, acc, mw, nw, lc, hi);
         else sp_plain_epilogue<MT, NT, false, false>(p, acc, mw, nw, lc, hi);
       }
@@ -547,6 +631,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
 #undef SP_TRACE_NEXT
 #undef SP_BODY
 #undef SP_STEP
+#undef SP_RES_MULT
+#undef SP_RES_ISSUE
 #endif
 }
 
@@ -568,6 +654,15 @@ static bool sp_eligible(const GemmParams& p) {
   if (p.residual && (!al16(p.residual) || p.ldr % 8 != 0)) return false;
   if (p.rowadd && (!al16(p.rowadd) || p.ldra % 8 != 0)) return false;
   return true;
+}
+
+// Residual through the matrix core (RESM, see the kernel): every 32 x 32 sub-tile of the wave tile needs a K tile of its own plus one, and
+// the residual is addressed through a buffer descriptor (32-bit byte offsets).  MD_SP_RESM = 0: the round-3 epilogue (A/B runs).
+template <int MT, int NT>
+static bool sp_resm(const GemmParams& p) {
+  static const int resm = md_env_int("MD_SP_RESM", 1);
+  return resm && p.residual && !p.bias_rows && !(SP_ABL & 32) && p.K / 64 >= MT * NT + 1 &&
+         ((unsigned long long)(p.M - 1) * p.ldr + p.N) * 2 < (1ull << 31);
 }
 
 template <bool CONV, bool GEGLU, int NT = GEGLU ? 4 : 5, int MT = GEGLU ? 4 : 3>
@@ -595,6 +690,13 @@ static void launch_sp(GemmParams& p, hipStream_t stream) {
   p.reverse = !CONV && !GEGLU && !p.bias_rows && big_a && (rev == 2 || (rev == 1 && p.K >= 4 * p.N));
   const int ncu = md_device_cus();
   const int grid = p.tiles_total < ncu ? p.tiles_total : ncu;
+  if constexpr (!GEGLU) {
+    if (sp_resm<MT, NT>(p)) {
+      md_ensure_dynamic_lds<gemm_sp_kernel<CONV, false, MT, NT, true>>((int)smem);
+      hipLaunchKernelGGL((gemm_sp_kernel<CONV, false, MT, NT, true>), dim3(grid), dim3(256), smem, stream, p);
+      return;
+    }
+  }
   hipLaunchKernelGGL((gemm_sp_kernel<CONV, GEGLU, MT, NT>), dim3(grid), dim3(256), smem, stream, p);
 }
 

@@ -76,6 +76,32 @@ for M, N, K in [(900, 640, 256), (900, 1280, 256), (900, 512, 256)]:
     wide = rnd(M, 2 * K, seed=8)
     check("lda", lambda: ops.gemm(d(wide)[:, K:], d(w)), wide[:, K:].float() @ w.float().t())
 
+# residual through the matrix core (RESM, round 6): K tiles > sub-tiles of the wave tile (K >= 1088 for 192 x 320), so the residual enters the
+# accumulators as identity MFMAs inside the K loop and the epilogue is the bias-only one.  Ragged M, several column tiles, 2-3 output tiles
+# per workgroup (420 / 1050 tiles), residual + row-broadcast term, in place, a strided residual; then the EXACT screen: A = 0 leaves
+# fp16(bias + residual), one rounding, bit for bit -- any row / column / sub-tile mix-up of the injected residual shows up as a mismatch.
+from mikudance_amd import _lib  # noqa: E402
+_plan = _lib.load().md_gemm_plan
+for M, N, K in [(900, 1280, 1280), (20000, 1280, 1088), (1000, 1280, 2560), (50000, 1280, 1152), (4608, 1280, 5120)]:
+    a, w = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=K ** -0.5)
+    bias, res, radd = rnd(N, seed=63), rnd(M, N, seed=64), rnd(10, N, seed=65)
+    rpg = -(-M // 10)
+    base = a.float() @ w.float().t() + bias.float()
+    if M >= 4608 and os.environ.get("MD_SP_RESM", "1") != "0":      # (the plan query answers for the automatic dispatch: enough tiles)
+        assert _plan(M, N, K, 0, 0, 5, 256) // 1000 == 2, "expected the residual-through-the-matrix-core flavour"
+    check(f"resm residual {M}x{N}x{K}", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(res)), base + res.float())
+    check("resm residual, no bias", lambda: ops.gemm(d(a), d(w), residual=d(res)), a.float() @ w.float().t() + res.float())
+    check("resm bias + residual + rowadd", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(res), rowadd=d(radd), rows_per_group=rpg),
+          base + res.float() + radd.float().repeat_interleave(rpg, 0)[:M])
+    hs = d(res).clone()
+    ops.gemm(d(a), d(w), bias=d(bias), residual=hs, out=hs)
+    check("resm residual in place", lambda: hs, base + res.float())
+    wide_r = rnd(M, N + 64, seed=66)
+    check("resm strided residual", lambda: ops.gemm(d(a), d(w), bias=d(bias), residual=d(wide_r)[:, 64:]), base + wide_r[:, 64:].float())
+    out0 = ops.gemm(torch.zeros(M, K, dtype=torch.float16, device=dev), d(w), bias=d(bias), residual=d(res))
+    assert torch.equal(out0.cpu(), (bias.float() + res.float()).half()), f"resm exact screen {M}x{N}x{K}"
+    print(f"ok  resm exact screen {M}x{N}x{K}")
+
 # transposed output (V^T for the attention kernels): the same kernels on swapped operands, bias along the output rows; M % 256 == 0
 for M, N, K, with_bias in [(2048, 320, 320, False), (8192, 640, 640, True), (4608, 1280, 1280, False), (512, 1280, 256, True), (73728, 320, 320, True)]:
     a, w = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5)
@@ -139,5 +165,15 @@ temb, res = rnd(2, c, seed=26), rnd(B, h, wd, c, seed=27)
 ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
 ref = ref + temb.float().repeat_interleave(2, 0)[:, None, None, :] + res.float()
 wpk = packing.conv3x3_weight(wt, dev)
+check("conv+res (resm)", lambda: ops.conv3x3(d(x), wpk, c, bias=d(bias), residual=d(res)), ref - temb.float().repeat_interleave(2, 0)[:, None, None, :])
 check("conv+temb+res", lambda: ops.conv3x3(d(x), wpk, c, bias=d(bias), residual=d(res), rowadd=d(temb), rows_per_group=2 * h * wd), ref)
+# a conv with residual whose 384 (or more) output tiles wrap the persistent grid: the resnet's second conv at the 96 x 96 level, 8 images
+B, c, h, wd = 8, 320, 96, 96
+x, wt, bias, res = rnd(B, h, wd, c, seed=71), rnd(c, c, 3, 3, seed=72, scale=(9 * c) ** -0.5), rnd(c, seed=73), rnd(B, h, wd, c, seed=74)
+ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1).permute(0, 2, 3, 1) + res.float()
+wpk = packing.conv3x3_weight(wt, dev)
+check("conv 96x96 + residual (resm, wrapped grid)", lambda: ops.conv3x3(d(x), wpk, c, bias=d(bias), residual=d(res)), ref)
+hs = d(res).clone()
+ops.conv3x3(d(x), wpk, c, bias=d(bias), residual=hs, out=hs)
+check("conv 96x96 + residual in place", lambda: hs, ref)
 print("ALL OK")

@@ -168,21 +168,22 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
     measured best on MI355X in same-box A/B runs (profiles/r03_ab_gemm_sp_tiles.log, r03_ab_gemm_sp_tile_128x256.log,
     r03_ab_transposed_sp.log).  md_gemm_plan / md_conv3x3_plan run the launcher's own decision code without
     touching a device: 135 / 134 / 124 / 132 / 142 = gemm_sp_kernel 192x320 / 192x256 / 128x256 / 192x128 / 256x128, 144 = its 256x256 GEGLU flavour, +1000 on
-    swapped operands (transposed output), 210 / 220 / 230 = W-stationary streaming kernel, 301 / 303 = multi-workgroup kernel."""
+    swapped operands (transposed output), +2000 when a residual enters through the matrix core (round 6: K tiles > sub-tiles of the wave tile -- FF-out, the
+    K >= 1280 out-projections, a resnet's second conv; short K keeps the epilogue form: 135), 210 / 220 / 230 = W-stationary streaming kernel, 301 / 303 = multi-workgroup kernel."""
     from mikudance_amd import _lib, ops
     lib = _lib.load()
     ncu, G = 256, ops.ACT_GEGLU
     gemm = {
         # level 0 (96 x 96): HBM-bound projections and the K = 320 GEGLU stream; FF-out on the big tile
-        (294912, 320, 320, 0, 0, 5): 210, (294912, 960, 320, 0, 0, 0): 210, (294912, 2560, 320, G, 0, 4): 230, (294912, 320, 1280, 0, 0, 5): 135,
+        (294912, 320, 320, 0, 0, 5): 210, (294912, 960, 320, 0, 0, 0): 210, (294912, 2560, 320, G, 0, 4): 230, (294912, 320, 1280, 0, 0, 5): 2135,
         # level 1 (48 x 48)
-        (73728, 640, 640, 0, 0, 5): 220, (73728, 5120, 640, G, 0, 4): 144, (73728, 640, 2560, 0, 0, 5): 135,
+        (73728, 640, 640, 0, 0, 5): 220, (73728, 5120, 640, G, 0, 4): 144, (73728, 640, 2560, 0, 0, 5): 2135,
         # level 2 (24 x 24): N = 1280 takes the 192 x 256 tile (480 tiles = 1.9 rounds instead of 384 = 1.5)
-        (18432, 1280, 1280, 0, 0, 5): 134, (18432, 10240, 1280, G, 0, 4): 144, (18432, 1280, 5120, 0, 0, 5): 134, (18432, 3840, 1280, 0, 0, 0): 135,
+        (18432, 1280, 1280, 0, 0, 5): 2134, (18432, 10240, 1280, G, 0, 4): 144, (18432, 1280, 5120, 0, 0, 5): 2134, (18432, 3840, 1280, 0, 0, 0): 135,
         (18432, 2560, 1280, 0, 0, 0): 135,
         # level 3 (12 x 12): N = 1280 on 192 x 128 tiles (24 x 10 = 240 of them fill 256 CUs; 128 x 256 gives 180): +14..16 % same-box
         # (profiles/r04_ab_tile_192x128.log); the wider N keep the 192 x 256 tile
-        (4608, 1280, 1280, 0, 0, 5): 132, (4608, 10240, 1280, G, 0, 4): 144, (4608, 1280, 5120, 0, 0, 5): 132, (4608, 2560, 1280, 0, 0, 0): 134,
+        (4608, 1280, 1280, 0, 0, 5): 2132, (4608, 10240, 1280, G, 0, 4): 144, (4608, 1280, 5120, 0, 0, 5): 2132, (4608, 2560, 1280, 0, 0, 0): 134,
         (4608, 3840, 1280, 0, 0, 0): 134,
         # V^T projections (transposed output): swapped operands
         (294912, 320, 320, 0, 1, 0): 1134, (73728, 640, 640, 0, 1, 0): 1124, (18432, 1280, 1280, 0, 1, 0): 1134, (4608, 1280, 1280, 0, 1, 0): 1124,
@@ -203,13 +204,16 @@ def test_gemm_and_conv_dispatch_table_of_the_benchmark_shapes():
     for (B, H, cin, cout, st, up), want in conv.items():
         got = lib.md_conv3x3_plan(B, H, H, cin, cout, st, up, 4, ncu)
         assert got == want, ((B, H, cin, cout, st, up), got, want)
+    # a resnet's second conv (bias + shortcut): the residual through the matrix core; K = 640 with a residual (10 K tiles < 15 sub-tiles): the epilogue form
+    assert lib.md_conv3x3_plan(32, 96, 96, 320, 320, 1, 0, 5, ncu) == 2135 and lib.md_conv3x3_plan(32, 24, 24, 1280, 1280, 1, 0, 5, ncu) == 2134
+    assert lib.md_gemm_plan(294912, 320, 640, 0, 0, 5, ncu) == 135 and lib.md_gemm_plan(294912, 320, 960, 0, 0, 5, ncu) == 135
     # argument errors are reported, not guessed around
     assert lib.md_gemm_plan(128, 320, 100, 0, 0, 0, ncu) < 0 and lib.md_conv3x3_plan(1, 8, 8, 60, 320, 1, 0, 0, ncu) < 0
     # configs[4]: 983 040 tokens.  K = 1280 makes A 2.5 GB, beyond the sp kernel's 2^31-byte reach: planned (and launched) in row blocks
-    assert lib.md_gemm_plan(983040, 320, 1280, 0, 0, 5, ncu) == 135 and lib.md_gemm_plan(983040, 320, 320, 0, 0, 5, ncu) == 210
+    assert lib.md_gemm_plan(983040, 320, 1280, 0, 0, 5, ncu) == 2135 and lib.md_gemm_plan(983040, 320, 320, 0, 0, 5, ncu) == 210
     assert lib.md_conv3x3_plan(60, 128, 128, 960, 320, 1, 0, 4, ncu) == 135
     # a smaller chip changes the rounds, hence the tile: the model is per device
-    assert lib.md_gemm_plan(18432, 1280, 1280, 0, 0, 5, 192) in (134, 135, 124)
+    assert lib.md_gemm_plan(18432, 1280, 1280, 0, 0, 5, 192) in (2134, 2135, 2124)
 
 
 def test_fused_normalisation_plans_are_the_measured_table():
