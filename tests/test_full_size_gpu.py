@@ -1,7 +1,12 @@
 """GPU, BASELINE.json configs[1] size: the kernels that are only selected at full size (the one-wave-per-SIMD GEMM / conv
 flavour of gemm_sp.h is chosen for >= 112 tiles of its 192 x 320 / 192 x 256 / 128 x 256 tile, and K >= 640 for plain GEMMs) against the small-tile kernels that the oracle parity tests
 cover, in situ: one whole DDIM step (reference UNet write pass, denoising UNet read pass with CFG, DDIM) with MD_GEMM_SP=0 and
-with the automatic selection must agree to fp16 accumulation-order noise: relative L2 <= 2e-3, cosine >= 0.99999."""
+with the automatic selection must agree to fp16 accumulation-order noise.  Until round 6 the two were BIT-IDENTICAL (every GEMM flavour sums
+its K steps in the same order; profiles/r06_ab_sp_resm.log), so the old bound of 2e-3 never measured anything.  Since the sp kernel takes
+its residual through the matrix core (the residual joins the fp32 sum after the second K tile instead of after the last: one-ulp flips in
+0.1-0.3 % of such an operator's outputs, tools/resm_diff.py) they differ by rounding noise, and this metric is harsh on it: ONE DDIM step
+from t = 999 is the x0 prediction, which multiplies every error of the predicted noise by 1 / sqrt(alpha_999) = 14.6.  Measured 4.2e-3 /
+0.999993 (MD_SP_RESM=0 restores 0.0 / 1.0); bound: relative L2 <= 1e-2, cosine >= 0.9999."""
 import os
 import subprocess
 import sys
@@ -28,7 +33,7 @@ def test_full_size_step_big_tile_vs_small_tile_kernels():
     assert a.shape == b.shape == (1, 4, 16, 96, 96)
     rel = float((a - b).norm() / a.norm())
     cos = float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))
-    assert rel <= 2e-3 and cos >= 0.99999, (rel, cos)
+    assert rel <= 1e-2 and cos >= 0.9999, (rel, cos)
 
 
 def test_config5_size_one_step_finite_and_deterministic(full):
