@@ -30,6 +30,10 @@ for what in sys.argv[1:] or ["conv", "gemm", "gemm_res"]:
         a = torch.randn(M, K, device=dev).half(); w = (torch.randn(Nn, K, device=dev) * K ** -0.5).half()
         r = torch.randn(M, Nn, device=dev).half(); b = torch.randn(Nn, device=dev).half()
         fn = (lambda: ops.gemm(a, w, bias=b)) if what.endswith("_nores") else (lambda: ops.gemm(a, w, bias=b, residual=r))
+    elif what == "conv_res":      # a resnet's second conv at the 96 x 96 level: bias + shortcut (45 K tiles per output tile)
+        x = torch.randn(32, 96, 96, 320, device=dev).half(); w = (torch.randn(320, 9 * 320, device=dev) * 0.02).half()
+        r = torch.randn(32, 96, 96, 320, device=dev).half(); b = torch.randn(320, device=dev).half()
+        fn = lambda: ops.conv3x3(x, w, 320, bias=b, residual=r)
     else:
         x = torch.randn(32, 96, 96, 320, device=dev).half(); w = (torch.randn(320, 9 * 320, device=dev) * 0.02).half()
         fn = lambda: ops.conv3x3(x, w, 320)
