@@ -187,7 +187,8 @@ int md_set_cu_limit(int ncu);
 /* Dispatch queries (no device access, nothing launched): which kernel the automatic dispatch of md_gemm_f16 / md_conv3x3_nhwc_f16
  * selects for a problem on a chip with `ncu` compute units, for dense 16-byte aligned operands.  epi: bit 0 residual, bit 1
  * row-broadcast operand, bit 2 bias.  Returns 1MN gemm_sp_kernel with wave tile (MT, NT) = (M, N) (135 = 192x320, 134 = 192x256,
- * 124 = 128x256, 132 = 192x128, 142 = 256x128, 144 = 256x256 GEGLU; +1000 on swapped operands for a transposed output), 210 / 220 / 230 the W-stationary
+ * 124 = 128x256, 132 = 192x128, 142 = 256x128, 144 = 256x256 GEGLU; +1000 on swapped operands for a transposed output, +2000 when the
+ * residual enters the accumulators through the matrix core inside the K loop instead of in the epilogue: K tiles > 32 x 32 sub-tiles of the wave tile), 210 / 220 / 230 the W-stationary
  * streaming kernel (K = 320 / K = 640 / GEGLU), 301 / 302 / 303 the multi-workgroup kernel (64-column / 256x128 / 128x128 tiles),
  * or a negative MD_ERR code.  They pin the measured dispatch table in CPU tests. */
 int md_gemm_plan(int M, int N, int K, int act, int transpose_out, int epi, int ncu);
