@@ -41,7 +41,7 @@
 #define WS_RES_DEPTH 4         // residual tiles in flight per store wave
 #endif
 #ifndef WS_RES_DEPTH_640
-#define WS_RES_DEPTH_640 WS_RES_DEPTH   // ... of the K = 640 flavour (2 pieces per lane and tile instead of 5: the registers allow more)
+#define WS_RES_DEPTH_640 8              // ... of the K = 640 flavour (2 pieces per lane and tile instead of 5: the registers allow more)
 #endif
 
 struct WsParams {
@@ -444,22 +444,11 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           for (int j = 0; j < 4; ++j) lsf[i][j] = s0[j], lsf[i][j + 4] = s1[j], lcf[i][j] = c0[j], lcf[i][j + 4] = c1[j];
         }
       }
-      constexpr int RD = RA ? 2 : Cfg::RES_DEPTH;     // residual tiles in flight per store wave (fewer when the row-broadcast term
-                                                      // also lives in registers: 256 VGPRs per wave)
+      constexpr int RD = RA ? (KS == 20 ? 4 : 2) : Cfg::RES_DEPTH;   // residual tiles in flight per store wave (fewer when the row-broadcast term
+                                                                // also lives in registers at K = 320: 5 pieces per lane and tile)
       static_assert(RD % TPR == 0, "residual buffers are indexed statically per unrolled round");
       constexpr int UNR = RD / TPR;                   // rounds per unrolled loop body
       half8_t res[RES ? RD : 1][SPL];
-      auto fetch_res = [&](half8_t (&dst)[SPL]) {     // the next tile of this stream in order; rp[] advances
-#pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-#if defined(WS_ABL_RES) && WS_ABL_RES == 2              // diagnostic build (results wrong by construction): the adds without the loads
-          dst[i] = half8_t{1, 1, 1, 1, 1, 1, 1, 1};
-#else
-          dst[i] = *reinterpret_cast<const half8_t*>(rp[i]);
-#endif
-          rp[i] += rstep;
-        }
-      };
       int cur_group = -1;
       float raf[RA ? SPL : 1][8];
       auto store_tile = [&](int tile, int buf, int lslot, const half8_t (&rs)[SPL]) {
@@ -477,6 +466,9 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) raf[i][j] = (float)ra[j];
             }
+            // the reload's latency is paid HERE, once per group change, with the wait the compiler's pass understands: left to the pass, the
+            // wait lands behind the merge of the two paths, i.e. as vmcnt(0) in front of EVERY tile's epilogue (residual fetches included)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             cur_group = g1 == g0 ? g0 : -1;
           }
         }
@@ -518,30 +510,91 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           cp[i] += cstep;
         }
       };
-      if constexpr (RES) {
+      // K = 640 only.  At K = 320 the counted loop is +4.5 % on the isolated launch (0.120 -> 0.115 ms) and +-0 inside the denoising loop, where those
+      // launches move A + C + R at the HBM rate either way (profiles/r06_ab_ws_store_loop.log); with two tiles per round it would also spill (256 VGPRs).
+      constexpr bool COUNTED = RES && KS == 20;
+      if constexpr (COUNTED) {
+        // Residual flavours (restructured in round 6).  Until then this loop fetched and stored under per-tile conditions (`tile < my_tiles`,
+        // `tile + RD < my_tiles`), and the compiler's wait-count pass, which has to be right on every path through such a loop, answered with
+        // `s_waitcnt vmcnt(1)` / `vmcnt(0)` in front of every tile's residual: the wave waited for ALL its outstanding operations -- the stores
+        // it had just issued and the residual tile it had requested for RD tiles later -- i.e. it exposed one HBM latency per tile, whatever the
+        // prefetch depth (profiles/r05_ab_ws_residual_stream.log: depth 4 -> 8 -> 16 changed nothing; the K = 640 flavour paid 0.022 ms per launch
+        // for its residual).  Now the steady state is free of conditions on memory operations: the fetch is unconditional (past the last tile it
+        // re-reads the last one: the pointer stops advancing), full rounds run in an unrolled sequence that is LEFT by a jump (never skipped
+        // into), and a partial last round is handled at the exit it belongs to, with its own static slot.  The pass then counts: in front of a
+        // tile's residual it leaves the (RD - 1) SPL younger fetches (plus the stores between them) in flight.
+        int nf = 0;                                   // tiles fetched so far (the next fetch is tile min(nf, my_tiles - 1))
+        auto fetch_next = [&](half8_t (&dst)[SPL]) {
+          const size_t step = nf + 1 < my_tiles ? rstep : 0;
 #pragma unroll
-        for (int j = 0; j < RD; ++j)
-          if (j < my_tiles) fetch_res(res[j]);        // tiles 0 .. RD-1
-      }
-      // barrier b_r (r = 0 .. rounds): afterwards the compute waves work on round r and this wave stores round r-1, then prefetches
-      // the residual of the tile RD places further into the buffer it has just freed (RD tile periods ahead: the HBM latency
-      // under load is several tile periods).  Unrolled by UNR rounds so that the residual buffers are addressed statically:
-      // tile t uses res[t % RD], and (r - 1) % UNR == (j + UNR - 1) % UNR because base % UNR == 0.
-      for (int base = 0; base <= rounds; base += UNR) {
+          for (int i = 0; i < SPL; ++i) {
+            dst[i] = *reinterpret_cast<const half8_t*>(rp[i]);
+            rp[i] += step;
+          }
+          ++nf;
+        };
 #pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-          const int r = base + j;
-          if (r <= rounds) {
-            __builtin_amdgcn_s_barrier();                             // b_r
-            if (r >= 1) {
+        for (int j = 0; j < RD; ++j) fetch_next(res[j]);                // tiles 0 .. RD-1
+        const int full = my_tiles / TPR;                                // rounds whose TPR tiles all exist
+        __builtin_amdgcn_s_barrier();                                   // b_0
+        int r = 1;                                                      // barrier b_r is followed by the stores of round r - 1
+        // body J of the unrolled sequence (J spelled out: the slots must be compile-time indices whatever the loop transformations do --
+        // with `#pragma unroll` over a loop that is left by goto the residual buffers ended up dynamically indexed, in scratch memory)
+#define WS_STORE_BODY(J)                                                                                    \
+        if constexpr ((J) < UNR) {                                                                          \
+          if (r > full) {                                                                                   \
+            if (r <= rounds) {       /* the partial last round (TPR = 2, odd tile count): its first tile only */ \
+              __builtin_amdgcn_s_barrier();                             /* b_rounds */                      \
+              store_tile((r - 1) * TPR, ((r - 1) & 1) * TPR, lslot_of(r - 1, 0), res[(J) * TPR]);           \
+            }                                                                                               \
+            goto ws_store_done;                                                                             \
+          }                                                                                                 \
+          __builtin_amdgcn_s_barrier();                                 /* b_r */                           \
+          _Pragma("unroll") for (int u = 0; u < TPR; ++u) {                                                 \
+            /* slot == tile % RD: r - 1 == J (mod UNR) */                                                   \
+            store_tile((r - 1) * TPR + u, ((r - 1) & 1) * TPR + u, lslot_of(r - 1, u), res[(J) * TPR + u]); \
+            fetch_next(res[(J) * TPR + u]);                                                                 \
+          }                                                                                                 \
+          ++r;                                                                                              \
+        }
+        static_assert(UNR <= 8, "WS_STORE_BODY is spelled out eight times");
+        for (;;) {
+          WS_STORE_BODY(0) WS_STORE_BODY(1) WS_STORE_BODY(2) WS_STORE_BODY(3) WS_STORE_BODY(4) WS_STORE_BODY(5) WS_STORE_BODY(6) WS_STORE_BODY(7)
+        }
+#undef WS_STORE_BODY
+      ws_store_done:;
+      } else {
+        // barrier b_r (r = 0 .. rounds): afterwards the compute waves work on round r and this wave stores round r-1, then (K = 320 residual
+        // flavour with two tiles per round) prefetches the residual of the tile RD places further into the buffer it has just freed.  Unrolled
+        // by UNR rounds so that the residual buffers are addressed statically: tile t uses res[t % RD].
+        auto fetch_res = [&](half8_t (&dst)[SPL]) {
 #pragma unroll
-              for (int u = 0; u < TPR; ++u) {
-                const int tile = (r - 1) * TPR + u;
-                const int slot_ = ((j + UNR - 1) % UNR) * TPR + u;    // == tile % RD, a compile-time value after unrolling
-                if (tile < my_tiles) {
-                  store_tile(tile, ((r - 1) & 1) * TPR + u, lslot_of(r - 1, u), res[RES ? slot_ : 0]);
-                  if constexpr (RES) {
-                    if (tile + RD < my_tiles) fetch_res(res[slot_]);
+          for (int i = 0; i < SPL; ++i) {
+            dst[i] = *reinterpret_cast<const half8_t*>(rp[i]);
+            rp[i] += rstep;
+          }
+        };
+        if constexpr (RES) {
+#pragma unroll
+          for (int j = 0; j < RD; ++j)
+            if (j < my_tiles) fetch_res(res[j]);        // tiles 0 .. RD-1
+        }
+        for (int base = 0; base <= rounds; base += UNR) {
+#pragma unroll
+          for (int j = 0; j < UNR; ++j) {
+            const int r = base + j;
+            if (r <= rounds) {
+              __builtin_amdgcn_s_barrier();                             // b_r
+              if (r >= 1) {
+#pragma unroll
+                for (int u = 0; u < TPR; ++u) {
+                  const int tile = (r - 1) * TPR + u;
+                  const int slot_ = ((j + UNR - 1) % UNR) * TPR + u;    // == tile % RD, a compile-time value after unrolling
+                  if (tile < my_tiles) {
+                    store_tile(tile, ((r - 1) & 1) * TPR + u, lslot_of(r - 1, u), res[RES ? slot_ : 0]);
+                    if constexpr (RES) {
+                      if (tile + RD < my_tiles) fetch_res(res[slot_]);
+                    }
                   }
                 }
               }
