@@ -60,6 +60,12 @@ typedef unsigned uint4_t __attribute__((ext_vector_type(4)));      // what the r
 
 // zeros standing in for an absent bias / row-broadcast operand (N <= 16384 columns: checked by sp_eligible)
 __device__ __attribute__((aligned(64))) half_t g_zero_cols[16384] = {};
+// where the 16-byte pieces of rows beyond M go (one slot per lane; only the last row tile of a ragged M has such rows).  The epilogues
+// store UNCONDITIONALLY, to a selected address: a store under `if (row < M)` is a memory operation the compiler's wait-count pass cannot
+// count on, so in front of the next column's bias / residual / row-term registers it planted waits that let only the younger LOADS fly --
+// i.e. every column waited until the previous column's stores had been ACKNOWLEDGED: 5 x ~1.9 k cycles, the "~10 k cycles" of a plain
+// 192 x 320 epilogue (profiles/r06_ab_sp_epilogue_waits.log).
+__device__ __attribute__((aligned(64))) half_t g_sp_dump[64 * 8];
 
 // One accumulator element, AGPR -> VGPR, at the point of use.  The "a" constraint keeps the MFMA accumulators in the accumulator
 // half of the register file for the whole kernel (left to itself the register allocator copies all 240-256 of them into
@@ -130,6 +136,7 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
     arow[i] = RA ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra + nw + 4 * hi : nullptr;
     crow[i] = p.C + (size_t)mc * p.ldc + nw + 8 * hi;
   }
+  half_t* const dump = g_sp_dump + ((lc + 32 * hi) << 3);
   SpColumn<MT, NT, RES, RA> col[LA + 1];
   auto request = [&](SpColumn<MT, NT, RES, RA>& d, int j, bool ahead) {
     if constexpr (!RB) {
@@ -204,10 +211,8 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
       for (int pr = 0; pr < 2; ++pr) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
-        if (row_ok[i]) {
-          const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
-          *reinterpret_cast<uint4*>(crow[i] + j * 32 + 16 * pr) = v4;
-        }
+        const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
+        *reinterpret_cast<uint4*>(row_ok[i] ? crow[i] + j * 32 + 16 * pr : dump) = v4;
       }
       __builtin_amdgcn_sched_barrier(0);                           // one sub-tile at a time: keeps the live ranges short
     }
@@ -560,20 +565,27 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
       if constexpr (GEGLU) {
         // sub-tile 2q is h, 2q+1 is g of the same outputs (weight rows packed as [32 h | 32 g] blocks)
+        // the bias of BOTH column pairs first: requested behind the stores of pair 0, pair 1's bias would be the youngest operation of the wave
+        // when it is needed, and the wait for it (vmcnt(0)) would also wait for those stores to be acknowledged
+        float2_t bh_[NT / 2][8], bg_[NT / 2][8];                    // pair c = 2 gi + e / 2: columns 8 gi + 4 hi + {e, e + 1}
 #pragma unroll
         for (int q = 0; q < NT / 2; ++q) {
-          const int nc = n0 + wn * (32 * NT) + q * 64;
-          const half_t* bias = (p.bias ? p.bias : g_zero_cols) + nc + 4 * hi;
-          float2_t bh[8], bg[8];                                  // pair c = 2 gi + e / 2: columns 8 gi + 4 hi + {e, e + 1}
+          const half_t* bias = (p.bias ? p.bias : g_zero_cols) + n0 + wn * (32 * NT) + q * 64 + 4 * hi;
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi) {
             const half4_t h4 = *reinterpret_cast<const half4_t*>(bias + 8 * gi);
             const half4_t g4 = *reinterpret_cast<const half4_t*>(bias + 32 + 8 * gi);
-            bh[2 * gi] = float2_t{(float)h4[0], (float)h4[1]};
-            bh[2 * gi + 1] = float2_t{(float)h4[2], (float)h4[3]};
-            bg[2 * gi] = float2_t{(float)g4[0], (float)g4[1]};
-            bg[2 * gi + 1] = float2_t{(float)g4[2], (float)g4[3]};
+            bh_[q][2 * gi] = float2_t{(float)h4[0], (float)h4[1]};
+            bh_[q][2 * gi + 1] = float2_t{(float)h4[2], (float)h4[3]};
+            bg_[q][2 * gi] = float2_t{(float)g4[0], (float)g4[1]};
+            bg_[q][2 * gi + 1] = float2_t{(float)g4[2], (float)g4[3]};
           }
+        }
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+          const int nc = n0 + wn * (32 * NT) + q * 64;
+          const float2_t (&bh)[8] = bh_[q];
+          const float2_t (&bg)[8] = bg_[q];
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * (32 * MT) + i * 32 + lc;
@@ -598,10 +610,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
             for (int pr = 0; pr < 2; ++pr) {
               const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
               const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
-              if (m < p.M) {
-                const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
-                *reinterpret_cast<uint4*>(drow + 16 * pr + 8 * hi) = v4;
-              }
+              const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
+              *reinterpret_cast<uint4*>(m < p.M ? drow + 16 * pr + 8 * hi : g_sp_dump + (lane << 3)) = v4;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
