@@ -125,7 +125,8 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
   bool row_ok[MT];
   const half_t* rrow[MT];
   const half_t* arow[MT];
-  half_t* crow[MT];
+  half_t* crow[MT][2];                   // store pointers: rows (lc & 15) and 16 + (lc & 15) of sub-tile row i, this lane's 16-byte chunk
+  bool crow_ok[MT][2];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = mw + i * 32 + lc;
@@ -134,7 +135,18 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
     rowb[i] = RB && p.bias ? (float)p.bias[mc] : 0.f;
     rrow[i] = RES ? p.residual + (size_t)mc * p.ldr + nw + 8 * hi : nullptr;
     arow[i] = RA ? p.rowadd + (size_t)(mc / p.rows_per_group) * p.ldra + nw + 4 * hi : nullptr;
-    crow[i] = p.C + (size_t)mc * p.ldc + nw + 8 * hi;
+    // Stores (round 6): 16 rows x 64 bytes per instruction instead of 32 rows x 32 bytes.  After the v_permlane32_swap pairing a lane holds
+    // the two 16-byte pieces (pr = 0, 1) of ITS row; one v_permlane16_swap per dword then gathers both pieces of rows 0-15 in one register
+    // set (lane l: row l & 15, piece (l >> 4) & 1, half hi) and those of rows 16-31 in the other: a row's four chunks sit in four lanes,
+    // the memory pipeline sees 64-byte runs, one request per row instead of two.  Measured (profiles/r06_ab_sp_epilogue_waits.log): the epilogue
+    // of a 192 x 320 tile is ~5.0 k cycles of arithmetic + ~4.5 k that appear with the stores; 64-byte runs take 0.1-1.3 k of the latter
+    // (+0.2 % end to end), non-temporal stores nothing (-0.35 % end to end: the consumer misses the memory-side cache).
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int mr = mw + i * 32 + 16 * h + (lc & 15);
+      crow_ok[i][h] = mr < p.M;
+      crow[i][h] = p.C + (size_t)(crow_ok[i][h] ? mr : p.M - 1) * p.ldc + nw + 16 * ((lc >> 4) & 1) + 8 * hi;
+    }
   }
   half_t* const dump = g_sp_dump + ((lc + 32 * hi) << 3);
   SpColumn<MT, NT, RES, RA> col[LA + 1];
@@ -207,12 +219,24 @@ __device__ __forceinline__ void sp_plain_epilogue(const GemmParams& p, const flo
         const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         __builtin_memcpy(w[gi], &o, 8);
       }
+      unsigned pc[2][4];                                             // piece pr of this lane's row: 8 columns
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
-        const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
-        *reinterpret_cast<uint4*>(row_ok[i] ? crow[i] + j * 32 + 16 * pr : dump) = v4;
+        pc[pr][0] = s0[0]; pc[pr][1] = s1[0]; pc[pr][2] = s0[1]; pc[pr][3] = s1[1];
+      }
+      unsigned lo[4], hi4[4];                                        // rows 0-15 / rows 16-31 of the sub-tile, both pieces
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const auto t = __builtin_amdgcn_permlane16_swap(pc[0][d], pc[1][d], false, false);
+        lo[d] = t[0]; hi4[d] = t[1];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint4 v4 = h ? uint4{hi4[0], hi4[1], hi4[2], hi4[3]} : uint4{lo[0], lo[1], lo[2], lo[3]};
+        if (SP_ABL & 64) asm volatile("" ::"v"(v4.x), "v"(v4.y), "v"(v4.z), "v"(v4.w));      // diagnostic: the arithmetic without the stores
+        else *reinterpret_cast<uint4*>(crow_ok[i][h] ? crow[i][h] + j * 32 : dump) = v4;
       }
       __builtin_amdgcn_sched_barrier(0);                           // one sub-tile at a time: keeps the live ranges short
     }
@@ -588,9 +612,12 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
           const float2_t (&bg)[8] = bg_[q];
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm * (32 * MT) + i * 32 + lc;
-            const int mc = m < p.M ? m : p.M - 1;
-            half_t* drow = p.C + (size_t)mc * p.ldc + (nc >> 1);
+            half_t* drow[2];                                        // rows (lc & 15) and 16 + (lc & 15): 64-byte runs per row (see sp_plain_epilogue)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int m = m0 + wm * (32 * MT) + i * 32 + 16 * h + (lc & 15);
+              drow[h] = m < p.M ? p.C + (size_t)m * p.ldc + (nc >> 1) + 16 * ((lc >> 4) & 1) + 8 * hi : g_sp_dump + (lane << 3);
+            }
             float2_t gl[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c)
@@ -606,13 +633,24 @@ __global__ __launch_bounds__(256, 1) void gemm_sp_kernel(GemmParams p) {
               const h2_t o = {(half_t)hv.x, (half_t)hv.y};
               __builtin_memcpy(&w[c >> 1][c & 1], &o, 4);
             }
+            unsigned pc[2][4];
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
               const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
               const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
-              const uint4 v4 = {s0[0], s1[0], s0[1], s1[1]};
-              *reinterpret_cast<uint4*>(m < p.M ? drow + 16 * pr + 8 * hi : g_sp_dump + (lane << 3)) = v4;
+              pc[pr][0] = s0[0]; pc[pr][1] = s1[0]; pc[pr][2] = s0[1]; pc[pr][3] = s1[1];
             }
+            uint4 vv[2];
+            {
+              const auto t0 = __builtin_amdgcn_permlane16_swap(pc[0][0], pc[1][0], false, false);
+              const auto t1 = __builtin_amdgcn_permlane16_swap(pc[0][1], pc[1][1], false, false);
+              const auto t2 = __builtin_amdgcn_permlane16_swap(pc[0][2], pc[1][2], false, false);
+              const auto t3 = __builtin_amdgcn_permlane16_swap(pc[0][3], pc[1][3], false, false);
+              vv[0] = uint4{t0[0], t1[0], t2[0], t3[0]};
+              vv[1] = uint4{t0[1], t1[1], t2[1], t3[1]};
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) *reinterpret_cast<uint4*>(drow[h]) = vv[h];
             __builtin_amdgcn_sched_barrier(0);
           }
         }
