@@ -444,6 +444,15 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           for (int j = 0; j < 4; ++j) lsf[i][j] = s0[j], lsf[i][j + 4] = s1[j], lcf[i][j] = c0[j], lcf[i][j + 4] = c1[j];
         }
       }
+#ifndef WS_PRE_WAIT
+#define WS_PRE_WAIT 1
+#endif
+      // The tables above are loop invariants requested ONCE, and the wait-count pass must know that they have landed before the tile loop:
+      // left to itself it covers their first use INSIDE the loop (flavours whose loop body starts with the row-term branch get no peeled
+      // first iteration), with the counts that are right on the entry path -- vmcnt(16) .. vmcnt(4) in front of the pieces of EVERY tile of
+      // the LayerNorm + row-term flavour (the motion module's q|k|v) -- and on every later tile those counts wait for the tile's own
+      // stores to be acknowledged: one store round trip per tile (profiles/r06_ab_ws_preamble_wait.log).
+      if constexpr (WS_PRE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
       constexpr int RD = RA ? (KS == 20 ? 4 : 2) : Cfg::RES_DEPTH;   // residual tiles in flight per store wave (fewer when the row-broadcast term
                                                                 // also lives in registers at K = 320: 5 pieces per lane and tile)
       static_assert(RD % TPR == 0, "residual buffers are indexed statically per unrolled round");

@@ -17,11 +17,26 @@ import torch
 import torch.distributed as dist
 
 
+def _forced():
+    """MD_DIST_FORCE=1: a ONE-rank job still builds its process group and sends every collective of this module through the backend
+    (RCCL on a GPU box): the only way to execute the RCCL code path -- scatter, gather, all_reduce, the object collectives, the
+    device-bound barrier -- on a machine with a single GPU (tools/r06_gpu.sh rccl1; profiles/r06_rccl_one_rank.json)."""
+    return os.environ.get("MD_DIST_FORCE") == "1"
+
+
+def active():
+    """True when the helpers below really communicate: more than one rank, or a forced one-rank group."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
+
+
 def init(backend=None):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not _forced():
         return 0, 1
+    if world == 1:                                          # forced one-rank group started without torchrun: its own rendezvous
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
     if not dist.is_initialized():
         backend = backend or os.environ.get("MD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
@@ -38,7 +53,7 @@ def shard(items, rank, world):
 def scatter_clips(clips, device, src=0):
     """clips: on `src` a list (one per rank) of tuples of tensors with identical shapes/dtypes across ranks; None
     elsewhere.  Returns this rank's tuple.  One dist.scatter per tensor slot."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return tuple(t.to(device) for t in clips[0])
     rank, world = dist.get_rank(), dist.get_world_size()
     meta = [None]
@@ -59,7 +74,7 @@ def scatter_clips(clips, device, src=0):
 
 def gather_latents(latents, dst=0):
     """Gather every rank's final latents on `dst` (list ordered by rank); other ranks get None."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return [latents]
     rank, world = dist.get_rank(), dist.get_world_size()
     device = latents.device
@@ -71,7 +86,7 @@ def gather_latents(latents, dst=0):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         if dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])     # the rank's own GPU (set in init), no device guessing
         else:
@@ -79,7 +94,7 @@ def barrier():
 
 
 def _reduce(value, device, op):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return value
     # fp32 on the wire (RCCL reduces it natively on every build; fp64 is the rarer code path and nothing here needs it)
     t = torch.tensor([value], dtype=torch.float32, device=device if dist.get_backend() == "nccl" else "cpu")
@@ -97,7 +112,7 @@ def sum_over_ranks(value, device):
 
 def gather_objects(obj, dst=0):
     """Small picklable per-rank records (timings, device identity) on `dst`, ordered by rank; None elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return [obj]
     bucket = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(obj, bucket, dst=dst)
@@ -151,7 +166,7 @@ class WindowParallel:
         return window_index % self.world == self.rank
 
     def reduce(self, noise_sum, counter):
-        if self.world == 1:
+        if self.world == 1 and not active():
             return
         if dist.get_backend(self.group) == "nccl":
             dist.all_reduce(noise_sum, group=self.group)

@@ -106,10 +106,14 @@ def test_two_rank_launch_protocol_under_gloo():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small",
                "--dry-run-cpu", "--size", "128", "--frames", "4", "--ddim-steps", "2"] + extra
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+        # MD_BENCH_TEST_BANNER: every rank printf()s a line to the C-level stdout the way RCCL does when its first communicator comes up (seen on
+        # MI355X: five lines that reach the file AFTER the JSON line, at exit); stdout must still hold the line and nothing else
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2", MD_BENCH_TEST_BANNER="1"))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout
+        assert r.stdout.strip().splitlines() == lines, r.stdout          # ... the LAST line of stdout is the first: a parser of either kind reads it
+        assert r.stderr.count("stand-in banner") == 2, r.stderr[-2000:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["clips_gathered"] == 2 and d["steps"] == 2 and d["warmup"] == 1
         assert d["value"] is None and "dry-run" in d["data"] and d["config"]["parallelism"] == "dp2"

@@ -12,6 +12,7 @@
 #   trace         tools/sp_trace.py (needs tools/ab/lib_trace.so) on the shapes in MD_TRACE
 #   ab            same-box end-to-end A/B of the libraries named in MD_AB="base cand" (tools/ab/lib_*.so), two rounds, family table
 #   abenv / abflag / kernenv   same-box A/B of one environment knob (MD_AB_ENV, MD_AB_VALUES) or one bench.py flag (MD_AB_FLAG) in ONE library; the knob on the micro-benchmarks
+#   rccl1                      one-rank job with a forced process group: every collective of dp.py through RCCL on one GPU
 #   ranks2 / queues            2-rank runs of bench.py on the one GPU (gloo); the two-queue proxy measurement
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-.}
@@ -105,6 +106,20 @@ ranks2)
   r2() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $1 bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-pmc "${@:3}" > $O/$2.json 2> $O/$2.err; echo "$2 rc=$?"; }
   r2 29511 bench_2rank_dp; r2 29512 bench_2rank_dp_scatter --scatter; r2 29513 bench_cfg4_2rank_window_parallel --config 4 --window-parallel
   summ $O/bench_2rank_dp.json $O/bench_2rank_dp_scatter.json $O/bench_cfg4_2rank_window_parallel.json ;;
+rccl1)
+  # ONE rank, process group forced (MD_DIST_FORCE=1): every collective of mikudance_amd/dp.py -- scatter, gather, all_reduce, gather_object, broadcast_object_list,
+  # the device-bound barrier -- goes through RCCL on the one GPU a lease has.  Proves the library loads and accepts the calls as made; says nothing about xGMI.
+  export MD_DIST_FORCE=1
+  B="--gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-pmc"
+  MASTER_PORT=29541 timeout 600 python bench.py $B --scatter > $O/rccl1_dp_scatter.json 2> $O/rccl1_dp_scatter.err; echo "rccl1 dp scatter rc=$?"
+  MASTER_PORT=29542 timeout 600 python bench.py $B --window-parallel > $O/rccl1_window_parallel.json 2> $O/rccl1_window_parallel.err; echo "rccl1 window-parallel rc=$?"
+  unset MD_DIST_FORCE
+  summ $O/rccl1_dp_scatter.json $O/rccl1_window_parallel.json
+  python -c "
+import json
+for f in ('$O/rccl1_dp_scatter.json', '$O/rccl1_window_parallel.json'):
+    d = json.loads(open(f).read().strip().splitlines()[-1]); m = d['multi_gpu']; print(f.split('/')[-1], m['collectives'], m['comm_ms_outside_timed_region'], m['mode'])
+"; tail -3 $O/rccl1_dp_scatter.err ;;
 queues)
   # one CFG clip / one guidance-free clip / two guidance-free clips from two processes / two CFG clips from two processes (profiles/r06_ab_two_queues.log)
   export MD_DIST_BACKEND=gloo
