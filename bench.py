@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the AutoencoderKL timing behind the extra keys vae_ms_per_clip / e2e_frames_per_s")
     ap.add_argument("--no-reuse", action="store_true", help="literal reference algorithm: reference UNet at every step on 2f frames")
     ap.add_argument("--no-share", action="store_true", help="A/B: evaluate conv_in + the first resnet of the denoising UNet on both CFG halves (literal)")
+    ap.add_argument("--two-queues", action="store_true", help="A/B: the CFG halves of the denoising UNet as two queues of B = f kernels instead of ONE queue of "
+                    "B = 2f kernels (the default; +0.2-0.35 percent, profiles/r06_ab_two_queue_halves.log)")
     ap.add_argument("--small", action="store_true", help="reduced-width UNets (debug only; NOT the benchmark)")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 owns the batch and scatters the per-clip conditioning inside "
                     "the timed region (default: every rank stages its own clip before it)")
@@ -125,6 +127,7 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
     pipe = MikuDanceVideoPipeline(None, None, ref, den, DDIMScheduler(**SCHED_KWARGS))
     pipe.reference_reuse = not args.no_reuse
     pipe.share_first_layers = not args.no_share
+    pipe.two_queues = bool(args.two_queues)
     h = w = args.size // 8
     setup_s = time.time() - t0
     # the plumbing test (CPU, gloo) replaces the kernels by a stand-in: launch, collectives, timing protocol and the JSON line
@@ -198,6 +201,9 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
     inst_elapsed = 0.0
     if rank == 0 and not dry:
         clip0 = staged[0] if args.scatter else staged
+        # the two clip-halves run as two kernel queues (pipe.two_queues): for THIS pass queue 1 waits for queue 0 -- the same launches, one at a
+        # time -- so that a launch's HIP events time that launch alone (side by side they would time whatever the other queue squeezed in)
+        den.serialize_queues = True
         _lib.PROFILER.start()
         sync()
         t1 = time.perf_counter()
@@ -206,6 +212,7 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
         sync()
         inst_elapsed = time.perf_counter() - t1
         _lib.PROFILER.stop()
+        den.serialize_queues = False
     dp.barrier()
 
     if rank != 0:
@@ -277,7 +284,9 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
                                   "camera_to_scene_motion + non-zero face/hand latents" if args.config == 2 else "")
                                + (", context 30 / overlap 8 -> 3 wrapping windows, 60-frame UNet batches" if args.config == 4 else ""),
                    "parallelism": (f"wp{world}" if wp else f"dp{world}"), "input_staging": "scatter from rank 0 inside the timed region" if args.scatter
-                   else "rank-local (every rank stages its own clip in HBM before the timed region)", "reference_reuse": pipe.reference_reuse, "weights": "random-init SD-1.5 geometry "
+                   else "rank-local (every rank stages its own clip in HBM before the timed region)", "reference_reuse": pipe.reference_reuse,
+                   "queues": "2 (unconditional | conditional half of the denoising UNet side by side)" if pipe.two_queues and pipe.share_first_layers and args.guidance > 1 else "1",
+                   "weights": "random-init SD-1.5 geometry "
                    "(N(0,1/fan_in), seeds 1234/4321)", "width": "reduced(debug)" if args.small else "full"},
         "executed_tflop_per_clip": total_flops / 1e12, "mfma_frac_whole_loop": total_flops / (elapsed / args.steps) / PEAK_MFMA_F16,
         "peak_hbm_gb": peak_gb, "kernel_ms_per_clip": kernel_ms, "instrumented_ms_per_step": inst_elapsed / inst_steps * 1e3, "setup_s": setup_s,

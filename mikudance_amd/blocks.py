@@ -228,9 +228,28 @@ class CrossContext:
         # src/pipelines/pipeline_mikudance.py:418-423 builds it with zeros_like).  For those rows K = V = 0 (to_k / to_v
         # have no bias), so the cross-attention output is exactly the to_out bias: see TransformerBlock.forward.
         self.zero_frames = zero_frames
+        self.root = self                  # the context whose K / V projections the blocks cache (slices share their root's)
+        self._slices = {}
+
+    def rows(self, lo, hi):
+        """The context as frames [lo, hi) of the batch see it (one CFG clip-half evaluated on its own queue): same padded rows, same cached
+        K / V projections (`root`), the frames' own index entries and what is left of the leading zero-context frames."""
+        s = self._slices.get((lo, hi))
+        if s is None:
+            s = CrossContext(self.ctx, self.index[lo:hi].contiguous(), self.lk, self.lpad, zero_frames=max(0, min(self.zero_frames, hi) - lo))
+            s.root = self.root
+            self._slices[(lo, hi)] = s
+        return s
 
 
 ZERO_CONTEXT_SKIP = True     # tests switch this off to compare against the literal evaluation
+
+# Which clip-half of a classifier-free-guidance batch the CURRENT call evaluates when the two halves run as two kernel queues
+# (UNet3DConditionModel.forward_nhwc, two_queues): None = the whole batch (rows [0, M/2) unconditional, the rest conditional);
+# 0 = unconditional rows only (the bank is ignored: reference src/models/mutual_mix_attention.py:181-201);
+# 1 = conditional rows only (every row reads the bank).  Set and reset by the UNet around each half's launches: the host enqueues
+# the two halves one after the other (one Python thread), only the GPU runs them side by side.
+CHAIN = None
 
 
 class TransformerBlock(_Packed):
@@ -270,16 +289,30 @@ class TransformerBlock(_Packed):
         self._kv_cache = None
         return pk
 
+    def context_kv(self, cross):
+        """(K, V^T, {row tables}) of the cross-attention context, projected once per context (keyed on the context's root OBJECT: the row
+        slices of a context that the two-queue evaluation hands to the clip-halves share their root's projections)."""
+        if self._kv_cache is None or self._kv_cache[0] is not cross.root:
+            pk = self.packed()
+            self._kv_cache = (cross.root, ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True), {})
+        return self._kv_cache[1:]
+
     def forward(self, h, B, L, cross):
         """h: [B*L, C] tokens.  Returns tokens."""
         pk = self.packed()
         C, H = self.dim, self.heads
         D = C // H
-        if self.ref_mode == "read" and len(self.bank) == 1:
+        if self.ref_mode == "read" and len(self.bank) == 1 and not (self.ref_cfg and CHAIN == 0):
             bank = self.bank[0]
             brows = bank.shape[0] * bank.shape[1] if bank.dim() == 3 else bank.shape[0]
             M = h.shape[0]
-            if self.ref_cfg:
+            if self.ref_cfg and CHAIN == 1:
+                # the conditional half on its own: every row reads the bank (the conditional frames' part of a literal 2f-frame bank)
+                begin, b2 = 0, bank.reshape(-1, C)
+                if brows == 2 * M:
+                    b2 = b2[M:]
+                assert b2.shape[0] == M, (b2.shape, M)
+            elif self.ref_cfg:
                 # unconditional rows (first half) ignore the bank (mutual_mix_attention.py:181-201)
                 begin = M // 2
                 b2 = bank.reshape(-1, C)
@@ -303,9 +336,7 @@ class TransformerBlock(_Packed):
             q, k = qk[:, :C], qk[:, C:]
             vt = ops.gemm(n, pk["v1"], transpose_out=True)
         a = ops.attention(q, k, vt, B, H, D, L, L)
-        if self._kv_cache is None or self._kv_cache[0] is not cross:
-            self._kv_cache = (cross, ops.gemm(cross.ctx, pk["k2"]), ops.gemm(cross.ctx, pk["v2"], transpose_out=True), {})
-        kv2 = self._kv_cache[1:]
+        kv2 = self.context_kv(cross)
         zf = min(cross.zero_frames, B) if ZERO_CONTEXT_SKIP else 0
         if zf:
             # frames with an all-zero context: cross-attention == to_out bias.  It rides on the attn1 out-projection as a

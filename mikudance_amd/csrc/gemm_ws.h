@@ -37,6 +37,9 @@
 // (K = 320: consecutive rows already shift by 8 slots) and r & 15 for 80 (K = 640): every ds_read_b128 of a 16-row x 32-k
 // fragment touches 16 distinct slots per lane group.
 #pragma once
+#ifndef WS_ABL
+#define WS_ABL 0               // DIAGNOSTIC builds only (tools/build_ab.sh, wrong results): 1 no MFMAs | 2 no fragment reads | 4 no global stores | 8 store waves idle |
+#endif                         // 16 no DMA after the first ring fill | 32 no staging writes   (profiles/r06_ws_ablation.log)
 #ifndef WS_RES_DEPTH
 #define WS_RES_DEPTH 4         // residual tiles in flight per store wave
 #endif
@@ -144,13 +147,20 @@ __device__ __forceinline__ half8_t ws_geglu_piece(const float* cs, int cs_ld, co
   const floatx4 g0 = *reinterpret_cast<const floatx4*>(s + 32), g1 = *reinterpret_cast<const floatx4*>(s + 36);
   half8_t o;
   float2_t gl[4];                         // pairs: the GELU polynomial runs on packed fp32, the four chains of a piece side by side
+  // pairs of ADJACENT columns: the LDS reads deliver them in consecutive registers and v_cvt_pk_f16_f32 wants them so (pairs (j, j + 4), until round 6, cost
+  // ten v_mov per piece; same arithmetic per element, same bits; no measurable difference: profiles/r06_ws_ablation.log)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) gl[j] = float2_t{g0[j] + q.bg[j], g1[j] + q.bg[j + 4]};
+  for (int j = 0; j < 2; ++j) {
+    gl[j] = float2_t{g0[2 * j] + q.bg[2 * j], g0[2 * j + 1] + q.bg[2 * j + 1]};
+    gl[j + 2] = float2_t{g1[2 * j] + q.bg[2 * j + 4], g1[2 * j + 1] + q.bg[2 * j + 5]};
+  }
   gelu_fast2_x<4>(gl);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    o[j] = (half_t)((h0[j] + q.bh[j]) * gl[j].x);
-    o[j + 4] = (half_t)((h1[j] + q.bh[j + 4]) * gl[j].y);
+  for (int j = 0; j < 2; ++j) {
+    o[2 * j] = (half_t)((h0[2 * j] + q.bh[2 * j]) * gl[j].x);
+    o[2 * j + 1] = (half_t)((h0[2 * j + 1] + q.bh[2 * j + 1]) * gl[j].y);
+    o[2 * j + 4] = (half_t)((h1[2 * j] + q.bh[2 * j + 4]) * gl[j + 2].x);
+    o[2 * j + 5] = (half_t)((h1[2 * j + 1] + q.bh[2 * j + 5]) * gl[j + 2].y);
   }
   return o;
 }
@@ -244,7 +254,11 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       const char* fb[P];
 #pragma unroll
       for (int j = 0; j < P; ++j) fb[j] = st + (rbase + ((4 * j + kq) ^ sw)) * 16;
+#if WS_ABL & 2
+      auto frag = [&](int ks) { return wf[0][ks]; };
+#else
       auto frag = [&](int ks) { return *reinterpret_cast<const half8_t*>(fb[ks % P] + (ks / P) * (16 << SWB)); };
+#endif
 #pragma unroll
       for (int j = 0; j < PD; ++j) af[j] = frag(j);
       __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);                         // PD ds_reads first ...
@@ -252,15 +266,25 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       for (int ks = 0; ks < KS; ++ks) {
         const half8_t cur = af[ks % PD];
         if (ks + PD < KS) af[ks % PD] = frag(ks + PD);
+#if WS_ABL & 1
+        asm volatile("" ::"v"(cur));
+#else
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb][ks], cur, acc[cb], 0, 0, 0);
+#endif
         if (ks + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ... then one refill per k step, issued
         __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                       //     ahead of that step's CB MFMAs
       }
       // acc[cb][r] = C[m = row][n = wave*16CB + cb*16 + 4*kq + r]
       float* cs = cst + buf * (TR * CS_LD) + row * CS_LD + wave * 16 * CB + 4 * kq;
+#if WS_ABL & 32
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) asm volatile("" ::"v"(acc[cb]));
+      (void)cs;
+#else
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<floatx4*>(cs + cb * 16) = acc[cb];
+#endif
     };
     for (int r = 0; r < rounds; ++r) {
       __builtin_amdgcn_s_barrier();                 // b_r: round r has landed; the staging tiles of parity r & 1 are free
@@ -341,6 +365,9 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
     if constexpr (PRO == PRO_AFF) load_table((tile0 * TR) / p.rows_per_image);      // before the first DMA is issued
     auto issue_round = [&](int q) {                 // called with q = 0, 1, 2, ... in order; tiles are issued in order too
       char* st = ring + (q % NR) * RSTAGE;
+#if WS_ABL & 16
+      if (q >= NR - 1) return;
+#endif
 #pragma unroll
       for (int u = 0; u < TPR; ++u) {
         if (q * TPR + u < my_tiles) {
@@ -463,6 +490,9 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
       auto store_tile = [&](int tile, int buf, int lslot, const half8_t (&rs)[SPL]) {
         const int m0 = (tile0 + tile * tstep) * TR;
         const float* cs = cst + buf * (TR * CS_LD);
+#if WS_ABL & 8
+        return;
+#endif
         if constexpr (RA) {
           // row-broadcast term: one table row per `rows_per_group` output rows (a frame); reloaded when the tile enters a new
           // group.  Tiles that straddle two groups take the per-piece path.
@@ -515,7 +545,11 @@ __global__ __launch_bounds__(512, 1) void wsgemm_kernel(WsParams p) {
           half8_t o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+#if WS_ABL & 4
+          asm volatile("" ::"v"(o));
+#else
           *reinterpret_cast<half8_t*>(cp[i]) = o;
+#endif
           cp[i] += cstep;
         }
       };

@@ -15,6 +15,7 @@ Result-preserving reductions (proven identical on the
   * unconditional rows ignore the bank -> one attention pass with a per-row K/V source replaces two.
 `reference_reuse=False` restores the literal per-step evaluation (same results, for A/B timing).
 """
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 
@@ -84,6 +85,11 @@ class MikuDanceVideoPipeline:
         self.vae_batch = 8                                                   # images per VAE call (the reference: 1)
         self.reference_reuse = True
         self.share_first_layers = True                                       # denoising UNet: conv_in + first resnet once for both CFG halves
+        # ... and, behind them, OPTIONALLY the unconditional and the conditional half as two kernel queues (UNet3DConditionModel._forward_two_queues;
+        # needs share_first_layers; pipe.two_queues = True or MD_TWO_QUEUES=1).  Off by default: on MI355X two queues of B = f kernels finish 7 % sooner
+        # than the same launches back to back, but one queue of B = 2f kernels is already that much more efficient -- +0.2-0.35 % end to end
+        # (profiles/r06_ab_two_queue_halves.log): measured, validated (tests/test_two_queues_gpu.py), not worth a second evaluation order by default
+        self.two_queues = os.environ.get("MD_TWO_QUEUES", "0") == "1"
         self._device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
     # ------------------------------------------------------------------------------------------ plumbing
@@ -197,7 +203,8 @@ class MikuDanceVideoPipeline:
                     cross = den._cross(embeds[:nb], [i // f for i in range(nb * f)], dev)
                     # both clip-halves are packed from the SAME latents (batch stride 0 above): the layers in front of the first attention
                     # run once (self.share_first_layers = False: the literal evaluation of both halves, bit-identical)
-                    pred = den.forward_nhwc(x, nb, f, torch.full((nb,), float(t)), cross, halves_identical=self.share_first_layers)
+                    pred = den.forward_nhwc(x, nb, f, torch.full((nb,), float(t)), cross, halves_identical=self.share_first_layers,
+                                            two_queues=self.two_queues)
                     ops.window_accumulate(pred, noise_sum, counter, win_dev[wi], f, F_, HW, halves=nb)
                     reader.clear()
                     writer.clear()

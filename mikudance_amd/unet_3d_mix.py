@@ -70,6 +70,17 @@ class _MidBlock(nn.Module):
             self.motion_modules = nn.ModuleList([MotionModule(c, **mm_kwargs)]) if motion else [None]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    """Two side streams per device for the two-queue evaluation of a CFG batch (created once; HIP maps them onto two hardware queues)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Stream(device=key))
+    return _SIDE_STREAMS[key]
+
+
 class _Skips:
     """Bookkeeping of the concat buffers during one forward (see _UNetBase._skip_plan)."""
 
@@ -308,12 +319,15 @@ class UNet3DConditionModel(_UNetBase):
         self._build(in_channels, tuple(block_out_channels), cross_attention_dim, norm_eps, flags, mm_kwargs, with_out=True)
 
     # ------------------------------------------------------------------------------------------ internal NHWC forward
-    def forward_nhwc(self, x, nb, f, timesteps, cross, halves_identical=False):
+    def forward_nhwc(self, x, nb, f, timesteps, cross, halves_identical=False, two_queues=False):
         """x: (nb*f, h, w, 64) fp16 (4 latent channels, zero padded); returns pred tokens [(nb*f*h*w), 4].
         halves_identical: the caller GUARANTEES that the two clip-halves of x hold the same latents (classifier-free guidance: the loop of
         src/pipelines/pipeline_mikudance.py:626-633 feeds `torch.cat([latents] * 2)`) -- with equal timesteps, conv_in and the first resnet
         (no attention in front of them: nothing has seen the context or the bank yet) then produce the same tensor for both halves, so
-        they run on ONE half and the result is copied (per-image arithmetic: bit-identical, tests/test_unets_gpu.py)."""
+        they run on ONE half and the result is copied (per-image arithmetic: bit-identical, tests/test_unets_gpu.py).
+        two_queues (with halves_identical): behind those shared layers the unconditional and the conditional half are independent all the way
+        to the output (per-image GroupNorm, per-row attention and LayerNorm, per-clip-half temporal attention: src/models/unet_3d_mix.py:
+        418-598, src/models/mutual_mix_attention.py:173-201), and they are evaluated as TWO KERNEL QUEUES (_forward_two_queues)."""
         pk = self.packed()
         dev = x.device
         _, hh, ww, _ = x.shape
@@ -322,32 +336,48 @@ class UNet3DConditionModel(_UNetBase):
         gf = 1 if self.use_inflated_groupnorm else f                        # plain nn.GroupNorm on 5-D: stats across frames
         B = x.shape[0]
         c0 = self.conv_in.weight.shape[0]
-        skips = _Skips(self._skip_plan())
         tt = torch.as_tensor(timesteps).reshape(-1)
         share = bool(halves_identical and nb == 2 and float(tt[0]) == float(tt[-1]))
+        b0 = self.down_blocks[0]
+        if share and two_queues and x.is_cuda and (b0.has_cross_attention or b0.motion_modules[0] is not None):
+            return self._forward_two_queues(x, f, trows, cross, pk, gf, force_size)
+        skips = _Skips(self._skip_plan())
+        first = None
         if share:
             slot = skips.slot(B, hh, ww, c0, dev)
             ops.conv3x3(x[:f], pk["cin"], c0, bias=pk["cinb"], out=slot[:f])
             slot[f:].copy_(slot[:f])
             x = slot
+            # the first resnet on one half (time rows of group 0 = those of group 1), then both halves from the copy
+            r = b0.resnets[0]
+            if b0.has_cross_attention or b0.motion_modules[0] is not None:
+                first = r(x[:f], self._temb(pk, trows, r), f * hh * ww, gf).repeat(2, 1, 1, 1)
+            else:                                                        # the resnet is its layer's last operator: it writes the skip in place
+                dst = skips.slot(B, hh, ww, r.cout, dev)
+                r(x[:f], self._temb(pk, trows, r), f * hh * ww, gf, out=dst[:f])
+                dst[f:].copy_(dst[:f])
+                first = dst
         else:
             x = ops.conv3x3(x, pk["cin"], c0, bias=pk["cinb"], out=skips.slot(B, hh, ww, c0, dev))
+        return tokens(self._body(x, skips, nb, f, trows, cross, pk, gf, force_size, first))
+
+    def _body(self, x, skips, nb, f, trows, cross, pk, gf, force_size, first=None, out=None):
+        """Everything behind conv_in.  x: conv_in's output (nb*f, h, w, C0), already in its skip slot; `first`: the first resnet's output when
+        the caller has evaluated it (shared between the clip-halves); `out`: where conv_out writes, (nb*f, h, w, 4)."""
+        dev = x.device
+        B = x.shape[0]
         for bi, blk in enumerate(self.down_blocks):
             for j, r in enumerate(blk.resnets):
                 H_, W_ = x.shape[1:3]
                 mm = blk.motion_modules[j]
-                dst = skips.slot(B, H_, W_, r.cout, dev)                 # the layer's LAST operator writes the skip in place
                 last_op = not (blk.has_cross_attention or mm is not None)
-                if share and bi == 0 and j == 0:
-                    # the first resnet on one half (time rows of group 0 = those of group 1), then both halves from the copy
-                    if last_op:
-                        r(x[:f], self._temb(pk, trows, r), f * H_ * W_, gf, out=dst[:f])
-                        dst[f:].copy_(dst[:f])
-                        x = dst
-                    else:
-                        x = r(x[:f], self._temb(pk, trows, r), f * H_ * W_, gf).repeat(2, 1, 1, 1)
+                if first is not None and bi == 0 and j == 0:
+                    x = first                                            # (written into its skip slot by the caller if it is the layer's last operator)
                 else:
+                    dst = skips.slot(B, H_, W_, r.cout, dev)             # the layer's LAST operator writes the skip in place
                     x = r(x, self._temb(pk, trows, r), f * H_ * W_, gf, out=None if not last_op else dst)
+                if not last_op and first is not None and bi == 0 and j == 0:
+                    dst = skips.slot(B, H_, W_, r.cout, dev)
                 if blk.has_cross_attention:
                     x = blk.attentions[j](x, cross, out=None if mm is not None else dst)
                 if mm is not None:
@@ -376,7 +406,71 @@ class UNet3DConditionModel(_UNetBase):
             if blk.upsamplers is not None:
                 x = blk.upsamplers[0](x, skips.top_hw() if force_size else None, out=skips.hidden_slot())
         x = groupnorm_frames(x, pk["ow"], pk["ob"], self.norm_eps, True, gf)
-        return tokens(ops.conv3x3(x, pk["co"], 4, bias=pk["cob"]))
+        return ops.conv3x3(x, pk["co"], 4, bias=pk["cob"], out=out)
+
+    def _forward_two_queues(self, x, f, trows, cross, pk, gf, force_size):
+        """The two clip-halves of a classifier-free-guidance batch as two kernel queues (stage B, without CU masks).
+
+        One queue of B = 2f kernels leaves the chip idle wherever a launch cannot fill it -- partial last rounds of the persistent GEMM / conv
+        grids, the 12 x 12 level, the tails of every launch -- and runs the HBM-class and the MFMA-class kernels strictly one after the other.
+        Two queues of B = f kernels fill each other's gaps (profiles/r06_ab_two_queues.log: two half-batch queues finish 8 % sooner than the
+        same launches back to back).  Layout of one call:
+          calling stream : time rows, conv_in and the first resnet on ONE half (shared: halves_identical); the cross-attention K / V of every
+                           block if this context is new (they are read by both queues); fork event
+          queue 0        : the unconditional half -- blocks.CHAIN = 0: no bank, zero-context rows (the to_out bias as a row term)
+          queue 1        : the conditional half   -- blocks.CHAIN = 1: every row reads the bank and the CLIP tokens
+          calling stream : waits for both; the prediction of both halves sits in ONE buffer allocated before the fork.
+        One Python thread enqueues queue 0, then queue 1 (the host runs several steps ahead of the GPU either way).  Memory: everything a queue
+        allocates comes from that stream's pool of the caching allocator; the few tensors that cross streams (first-resnet output, time rows, the
+        prediction buffer, conv_in's skip) are allocated on the calling stream BEFORE the fork and referenced until AFTER the join, and the
+        calling stream allocates nothing in between.  Per-layer tables that are built lazily on first use (folded LayerNorms, positional row
+        tables per (halves, frames)) would be built by queue 0 and read by queue 1: the FIRST two-queue call per latent shape therefore
+        runs its queues one after the other (queue 1 waits for queue 0's end), every later one side by side.
+        Results: each half goes through the same kernels with B = f instead of B = 2f; where the tile dispatch picks another flavour for the
+        smaller problem the fp32 summation order differs (bits may differ from the one-queue evaluation, error against fp32 is the same:
+        tests/test_two_queues_gpu.py); run to run the two-queue evaluation is bitwise reproducible (no atomics, no order dependence)."""
+        from . import blocks
+        dev = x.device
+        _, hh, ww, _ = x.shape
+        c0 = self.conv_in.weight.shape[0]
+        main = torch.cuda.current_stream(dev)
+        qs = _side_streams(dev)
+        plan = self._skip_plan()
+        sk = [_Skips(plan), _Skips(plan)]
+        slot0 = sk[0].slot(f, hh, ww, c0, dev)
+        ops.conv3x3(x[:f], pk["cin"], c0, bias=pk["cinb"], out=slot0)
+        r = self.down_blocks[0].resnets[0]
+        first = r(slot0, self._temb(pk, trows[0:1], r), f * hh * ww, gf)
+        for tb in self.transformer_blocks_in_order():
+            tb.context_kv(cross)
+        pred = torch.empty((2 * f, hh, ww, 4), device=dev, dtype=torch.float16)
+        primed = pk.setdefault("_two_queue_shapes", set())
+        serial = (f, hh, ww) not in primed or getattr(self, "serialize_queues", False)     # serialize_queues: bench.py's per-launch timing pass
+        fork = torch.cuda.Event()
+        fork.record(main)
+        done = []
+        for c in (0, 1):
+            with torch.cuda.stream(qs[c]):
+                qs[c].wait_event(fork)
+                if c == 1:
+                    if serial:
+                        qs[1].wait_event(done[0])
+                    slot1 = sk[1].slot(f, hh, ww, c0, dev)
+                    slot1.copy_(slot0)
+                blocks.CHAIN = c
+                try:
+                    self._body(slot0 if c == 0 else slot1, sk[c], 1, f, trows[c:c + 1], cross.rows(c * f, (c + 1) * f), pk, gf, force_size,
+                               first=first, out=pred[c * f:(c + 1) * f])
+                finally:
+                    blocks.CHAIN = None
+                ev = torch.cuda.Event()
+                ev.record(qs[c])
+                done.append(ev)
+        for ev in done:
+            main.wait_event(ev)
+        primed.add((f, hh, ww))
+        del first, slot0                                                  # (referenced up to here: see above)
+        return tokens(pred)
 
     # ------------------------------------------------------------------------------------------ reference-compatible forward
     @torch.no_grad()

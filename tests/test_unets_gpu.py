@@ -188,6 +188,7 @@ def test_layers_in_front_of_the_first_attention_run_once_for_both_cfg_halves(sma
                            (full[:2], tuple(x.half().cuda() for x in synth_inputs(4, 96, 96, ctx_len=257, ctx_dim=768, seed=3)) + (1, 3.5))):
         pipe = MikuDanceVideoPipeline(None, None, r_, d_, DDIMScheduler(**SCHED_KWARGS))
         assert pipe.share_first_layers
+        pipe.two_queues = False             # (the default) one queue of B = 2f kernels on both sides: the two-queue evaluation (B = f kernels) has its own test
         a = pipe.denoise(*args)
         pipe.share_first_layers = False
         b = pipe.denoise(*args)

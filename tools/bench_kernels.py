@@ -74,6 +74,17 @@ def main(which):
             tb = ops.groupnorm_table(x, g, b, 32, 1e-6)
             t_a = timeit(lambda: ops.gemm_affine(x, tb, w, bias=bias, out=o))
             print(f"{'gn+gemm ' + str(B) + 'x' + str(HW) + 'x' + str(C):40s} groupnorm {t_n:6.3f} + gemm {t_g:6.3f} = {t_n + t_g:6.3f} ms | table {t_t:6.3f} + affine gemm {t_a:6.3f} = {t_t + t_a:6.3f} ms")
+    if "wsk" in which:         # the W-stationary streaming kernel's flavours one by one (ablation builds: tools/r06_gpu.sh kernab)
+        for M, N, K, res, ra, geglu in [(294912, 960, 320, False, False, False), (294912, 960, 320, False, True, False), (294912, 320, 320, False, False, False),
+                                        (294912, 320, 320, True, False, False), (73728, 640, 640, False, False, False), (73728, 640, 640, True, False, False),
+                                        (73728, 1920, 640, False, True, False), (294912, 2560, 320, False, False, True)]:
+            a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+            r = rnd(M, N) if res else None
+            tab = rnd(32, N) if ra else None
+            o = torch.empty((M, N // 2 if geglu else N), device=dev, dtype=torch.float16)
+            ms = timeit(lambda: ops.gemm(a, w, bias=b, residual=r, rowadd=tab, rows_per_group=M // 32 if ra else 0, act=ops.ACT_GEGLU if geglu else 0, out=o))
+            byts = 2.0 * (M * K + M * (N // 2 if geglu else N) * (2 if res else 1))
+            out[f"gemm {M}x{N}x{K}{' +res' if res else ''}{' +rowadd' if ra else ''}{' geglu' if geglu else ''}"] = (ms, 2.0 * M * N * K / ms / 1e9, byts / ms / 1e6)
     if "tgemm" in which:       # transposed-output projections (V^T for the attention kernels)
         for M, N, K in [(294912, 320, 320), (73728, 640, 640), (18432, 1280, 1280), (4608, 1280, 1280), (147456, 320, 320)]:
             a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)

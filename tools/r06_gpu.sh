@@ -11,6 +11,7 @@
 #   kern ARGS     tools/bench_kernels.py with MD_KERN="gemm shapes ..." (30 iterations)
 #   trace         tools/sp_trace.py (needs tools/ab/lib_trace.so) on the shapes in MD_TRACE
 #   ab            same-box end-to-end A/B of the libraries named in MD_AB="base cand" (tools/ab/lib_*.so), two rounds, family table
+#   kernab                     tools/bench_kernels.py $MD_KERN under each library of MD_AB
 #   abenv / abflag / kernenv   same-box A/B of one environment knob (MD_AB_ENV, MD_AB_VALUES) or one bench.py flag (MD_AB_FLAG) in ONE library; the knob on the micro-benchmarks
 #   rccl1                      one-rank job with a forced process group: every collective of dp.py through RCCL on one GPU
 #   ranks2 / queues            2-rank runs of bench.py on the one GPU (gloo); the two-queue proxy measurement
@@ -97,6 +98,14 @@ abflag)
   for r in 1 2; do for f in "$MD_AB_FLAG" ""; do
     timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-pmc $f 2>/dev/null > $O/ab.json; echo "== flag '${f:-(none)}' (round $r)"; summ $O/ab.json
   done; done 2>&1 | tee $O/ab.log ;;
+kernab)
+  # micro-benchmarks (tools/bench_kernels.py $MD_KERN) under each library of MD_AB (tools/ab/lib_*.so): ablation / A-B builds at the kernel level
+  cp mikudance_amd/libmdance_hip.so /tmp/lib_keep.so
+  for v in $MD_AB; do
+    cp tools/ab/lib_$v.so mikudance_amd/libmdance_hip.so
+    echo "== $v"; MD_ITERS=${MD_ITERS:-30} MD_WARM=5 timeout 300 python tools/bench_kernels.py ${MD_KERN:-fused} 2>&1 | grep -v amdgpu | grep -E "gemm|conv|attn|norm|temporal"
+  done > $O/kernab.log 2>&1
+  cp /tmp/lib_keep.so mikudance_amd/libmdance_hip.so; cat $O/kernab.log ;;
 kernenv)
   for r in 1 2; do for v in ${MD_AB_VALUES:-0 1}; do echo "== ${MD_AB_ENV}=$v (round $r)"; env ${MD_AB_ENV:-MD_NONE}=$v MD_ITERS=30 MD_WARM=5 timeout 400 python tools/bench_kernels.py ${MD_KERN:-gemm skinny} 2>&1 | grep -v amdgpu | grep -E "gemm|conv|attn|norm|temporal"; done; done > $O/kern.log 2>&1; cat $O/kern.log ;;
 ranks2)
