@@ -39,8 +39,21 @@ FULL = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
 _LINE_OUT = None
 
 
+def flush_c_stdio():
+    """Whatever a native library has left in the C-level stdio buffers (RCCL's banner) goes out NOW -- to stderr, where main() has pointed file
+    descriptor 1 -- and not at exit: a caller that captures stdout and stderr into ONE stream then still finds the JSON line last."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                        # noqa: BLE001 -- cosmetics must never fail a benchmark
+        pass
+
+
 def emit_line(text):
     """The bench line, on the process's REAL stdout (main() points file descriptor 1 at stderr for everything else)."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    flush_c_stdio()
     out = _LINE_OUT or sys.stdout
     out.write(text + "\n")
     out.flush()
@@ -164,6 +177,7 @@ def _main_rank(args, rank, world, dp, _lib, DDIMScheduler, MikuDanceVideoPipelin
     sync()
     dp.barrier()
     sync()
+    flush_c_stdio()                                                  # every rank: the communicator exists by now, its banner is in the buffer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = run(staged)

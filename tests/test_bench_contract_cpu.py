@@ -95,6 +95,18 @@ def test_command_line_defaults():
     assert re.search(r'"--frames", type=int, default=16\b', src) and re.search(r'"--ddim-steps", type=int, default=20\b', src)
 
 
+def test_json_line_is_last_even_when_stdout_and_stderr_are_captured_as_one_stream():
+    """A native library's banner (RCCL prints one through the C-level stdio when its first communicator comes up) must not trail the JSON line:
+    bench.py points fd 1 at stderr, flushes the C buffers before it writes the line to the real stdout, and nothing is left for exit."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--small", "--dry-run-cpu", "--size", "128", "--frames", "4",
+           "--ddim-steps", "2"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="2", MD_BENCH_TEST_BANNER="1"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert "stand-in banner" in r.stdout and lines[-1].startswith("{") and json.loads(lines[-1])["n_gpus"] == 1, r.stdout[-2000:]
+
+
 def test_two_rank_launch_protocol_under_gloo():
     """bench.py exactly as the driver launches it for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2 ...), on CPU
     with the gloo backend and the kernels replaced by a stand-in (--dry-run-cpu): rendezvous, rank-local staging AND the
